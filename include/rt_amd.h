@@ -1,0 +1,215 @@
+/*
+ * rt_amd.h -- C ABI of librt_amd.so, the MI355X (gfx950) path-tracing backend that
+ * replaces the CUDA.jl path of rafaellg79/raytracing at its single device seam:
+ * the `gpu=true` branch of render() (main.jl:34-38) -> draw!(::CuArray, ...)
+ * (src/Ray_Tracing.jl:141-157).  Everything below that seam (draw_kernel, cu_trace,
+ * cu_hit, scatter, emit; src/Ray_Tracing.jl:51-69,102-139, src/cuscene_manager.jl,
+ * src/cuBVH.jl, src/mesh.jl:165-215) is implemented by hand-written HIP kernels.
+ *
+ * Conventions: every entry point is extern "C", takes plain pointers and sizes,
+ * returns 0 (RT_OK) or a negative rtStatus, never throws, never calls back into the
+ * host language and never exits the process.  rt_last_error() gives the message of
+ * the last failure on the calling thread.  The library copies every input buffer
+ * during rt_scene_create(); the caller owns all inputs and may free them on return.
+ * One rtScene lives on one GPU (one process per GPU; spp shards are summed by the
+ * host with an RCCL all-reduce between rt_render_accumulate and rt_finalize).
+ * A handle is not re-entrant; distinct handles may be used concurrently.
+ *
+ * Pixel layout of every image buffer: the memory order of a Julia
+ * Array{RGB{Float32},2}(H, W): float index ((col*H) + row)*3 + c, row 0 = top
+ * (src/Ray_Tracing.jl:92,130-132).
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rtStatus {
+    RT_OK = 0,
+    RT_EINVAL = -1,
+    RT_ENODEV = -2,
+    RT_ENOMEM = -3,
+    RT_EHIP = -4,
+    RT_EUNSUPPORTED = -5
+} rtStatus;
+
+/* object kinds: one per concrete Hittable of the reference */
+enum {
+    RT_SPHERE = 1,          /* src/sphere.jl:3   p = cx,cy,cz,r */
+    RT_MOVING_SPHERE = 2,   /* src/sphere.jl:12  p = c0(3),t0,c1(3),t1,r */
+    RT_XY_RECT = 3,         /* src/aarect.jl:3   p = x0,x1,y0,y1,k */
+    RT_XZ_RECT = 4,         /* src/aarect.jl:13  p = x0,x1,z0,z1,k */
+    RT_YZ_RECT = 5,         /* src/aarect.jl:23  p = y0,y1,z0,z1,k */
+    RT_BOX = 6,             /* src/box.jl:3      p = p0(3),p1(3) */
+    RT_TRANSFORM = 7,       /* src/transform.jl:3  child = wrapped object, aux = transform index */
+    RT_CONSTANT_MEDIUM = 8, /* src/constant_medium.jl:3  child = boundary, material = phase function, p[0] = neg_inv_density */
+    RT_BVH = 9,             /* src/BVH.jl:12 used as an object (samples/cover_the_next_week.jl:75,82)  aux = group index */
+    RT_MESH = 10            /* src/mesh.jl:5     aux = mesh index */
+};
+
+/* src/material.jl:3-9 */
+enum { RT_LAMBERTIAN = 1, RT_METAL = 2, RT_DIELECTRIC = 3, RT_EMISSIVE = 4, RT_ISOTROPIC = 5 };
+
+/* src/texture.jl:8-37 */
+enum { RT_TEX_SOLID = 0, RT_TEX_CHECKER = 1, RT_TEX_IMAGE = 2, RT_TEX_NOISE_MARBLE = 3, RT_TEX_NOISE_SCALAR = 4 };
+
+typedef struct rtObject {
+    int32_t kind;
+    int32_t material; /* index into materials, -1 if none */
+    int32_t child;    /* index into objects, -1 if none */
+    int32_t aux;
+    float p[12];
+} rtObject;
+
+typedef struct rtTransform { /* src/transform.jl:3-8 */
+    float xform[12];         /* 3x4 column-major 12-tuple, src/transform.jl:65 */
+    float inv_xform[12];
+    float bbox[6];           /* min(3), max(3) */
+} rtTransform;
+
+typedef struct rtMaterial { /* src/material.jl:11-16 */
+    int32_t type;
+    int32_t texture;
+    float fuzz;
+    float eta;
+} rtMaterial;
+
+typedef struct rtTexture {
+    int32_t kind;
+    int32_t a; /* checker: odd texture; image: image index; noise: perlin index */
+    int32_t b; /* checker: even texture */
+    int32_t pad;
+    float color[3];
+    float scale;
+} rtTexture;
+
+typedef struct rtImage { /* src/texture.jl:23-25, decoded by the host */
+    int32_t width, height;
+    const uint8_t* rgb; /* row-major, row 0 = top, 3 bytes per texel */
+} rtImage;
+
+typedef struct rtPerlin { /* src/perlin.jl:5-10 with point_count = 256 */
+    float ranvec[256 * 3];
+    int32_t perm_x[256], perm_y[256], perm_z[256];
+} rtPerlin;
+
+typedef struct rtMesh { /* src/mesh.jl:5-9 */
+    int32_t n_vertices, n_triangles, n_materials, pad;
+    const float* vertices;    /* 8 floats per vertex: position, normal, u, v (src/vertex.jl:3-8) */
+    const int32_t* indices;   /* 4 x n_triangles column-major, 0-based, in the order the BVH build left them (src/mesh.jl:237) */
+    const int32_t* materials; /* local material id -> index into materials */
+    const int32_t* tri_ids;   /* optional: original triangle id of each column (reported as sub_id); NULL = identity */
+} rtMesh;
+
+/* One BVHTree as the host built it (src/BVH.jl:65-109, src/mesh.jl:217-305): node ids are
+ * 1-based, slot i-1 describes node i, unused slots are never reached from node 1.
+ * kind 0: leaf.left == leaf.right == 1-based position in `objects`.
+ * kind 1 (vector of meshes): a mesh-level leaf has left = id of the mesh's triangle root and
+ * right = 1-based position of the mesh in `objects`; a triangle-level leaf has left..right =
+ * 1-based inclusive range of columns of that mesh's index matrix. */
+typedef struct rtBvh {
+    int32_t kind;
+    int32_t n_objects;
+    const int32_t* objects;   /* object indices in tree order (tree.objects after the build permuted it) */
+    int32_t n_nodes;          /* number of node slots */
+    int32_t pad;
+    const float* node_bounds; /* 6 per slot: min(3), max(3) */
+    const int32_t* node_left;
+    const int32_t* node_right;
+    const uint8_t* node_leaf;
+} rtBvh;
+
+typedef struct rtSceneDesc {
+    int32_t n_objects;    const rtObject* objects;
+    int32_t n_top;        const int32_t* top;      /* the `world` vector of render(): prim_id = position here */
+    int32_t n_transforms; const rtTransform* transforms;
+    int32_t n_materials;  const rtMaterial* materials;
+    int32_t n_textures;   const rtTexture* textures;
+    int32_t n_images;     const rtImage* images;
+    int32_t n_perlins;    const rtPerlin* perlins;
+    int32_t n_meshes;     const rtMesh* meshes;
+    int32_t n_groups;     const rtBvh* groups;     /* BVHTree objects referenced by RT_BVH.aux */
+    int32_t n_buckets;    const rtBvh* buckets;    /* SceneManager tuple, in order (src/scene_manager.jl:9-19,36-38) */
+} rtSceneDesc;
+
+typedef struct rtCamera { /* src/camera.jl:3-14, passed by value to draw_kernel in the reference */
+    float origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    float lens_radius, t0, t1;
+} rtCamera;
+
+typedef struct rtStats {
+    double seconds;       /* device time of the accumulate + finalize kernels */
+    uint64_t paths;       /* trace() calls = W*H*samples */
+    uint64_t rays;        /* hit(scene, ray) calls; 0 unless RT_FLAG_COUNTERS */
+    uint64_t node_visits; /* BVH nodes fetched and slab-tested; 0 unless RT_FLAG_COUNTERS */
+    uint64_t prim_tests;  /* leaf primitive tests; 0 unless RT_FLAG_COUNTERS */
+} rtStats;
+
+#define RT_FLAG_COUNTERS 1u /* run the counting variant of the kernel (slower) */
+
+typedef struct rtScene rtScene;
+
+int rt_abi_version(void);
+const char* rt_last_error(void);
+int rt_device_count(int* count);
+
+/* replaces CuSceneManager(bvh) / cu(::BVHTree) (src/cuscene_manager.jl:16-19, src/cuBVH.jl:20-22,
+ * src/mesh.jl:24-43): flattens the host trees into the device layout and uploads it to `device`. */
+int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out);
+int rt_scene_destroy(rtScene* scene);
+
+/* replaces draw!(img::CuArray, world, camera; background, pattern) (src/Ray_Tracing.jl:141-157) on one GPU:
+ * renders all n pattern columns, divides by n, takes the per-channel sqrt and copies the image to host
+ * memory `out` (3*H*W floats).  Blocking.  flags: RT_FLAG_*. */
+int rt_render(rtScene* scene, const rtCamera* camera, const float* pattern /* 2 x n column-major, host */, int n,
+              const float background[3], int width, int height, int max_depth, uint64_t seed, uint32_t flags,
+              float* out, rtStats* stats);
+
+/* The two halves of rt_render for spp sharding across GPUs (one process per GPU):
+ * rt_render_accumulate replaces the @cuda draw_kernel launch (src/Ray_Tracing.jl:151): it WRITES to the device
+ * buffer d_accum (3*H*W floats) the un-normalised sum of trace() over pattern columns sample_first,
+ * sample_first + sample_stride, ... < n.  rt_finalize replaces `img ./= N; sqrt` (src/Ray_Tracing.jl:152-153):
+ * d_out[i] = sqrt(d_accum[i] * Float32(1/n_total)).  Both enqueue on `stream` (a hipStream_t, NULL = default
+ * stream) and return without synchronising.  d_accum and d_out may alias. */
+int rt_render_accumulate(rtScene* scene, const rtCamera* camera, const float* pattern, int n, int sample_first,
+                         int sample_stride, const float background[3], int width, int height, int max_depth,
+                         uint64_t seed, uint32_t flags, float* d_accum, void* stream);
+int rt_finalize(rtScene* scene, const float* d_accum, int n_total, int width, int height, float* d_out, void* stream);
+/* counters of the last rt_render_accumulate with RT_FLAG_COUNTERS (synchronises the stream) */
+int rt_get_counters(rtScene* scene, rtStats* stats);
+
+/* Parity hooks.  rt_trace_rays: closest hit of fixed rays against the whole scene = hit(::SceneManager, ray,
+ * t_min, t_max) (src/scene_manager.jl:40-53 / src/cuscene_manager.jl:48-50).  rays: 7 floats each (origin,
+ * direction, time), host memory.  Outputs (host, any may be NULL): prim_id = position in `top` (-1 = miss),
+ * sub_id = box side 0..5 / triangle id / nested object index, t, normal(3), uv(2), front_face. */
+int rt_trace_rays(rtScene* scene, const float* rays, int n, float t_min, float t_max, uint64_t seed, int32_t* prim_id,
+                  int32_t* sub_id, float* t, float* normal, float* uv, uint8_t* front);
+/* radiance of single paths = trace(get_ray(camera, s, t), scene) (src/Ray_Tracing.jl:83-88) for n_paths
+ * triples (i = column, j = row counted from the bottom, sample) -> 3 floats each, host memory. */
+int rt_trace_paths(rtScene* scene, const rtCamera* camera, const float* pattern, int n, const float background[3],
+                   int width, int height, int max_depth, uint64_t seed, const int32_t* ids, int n_paths,
+                   float* radiance);
+
+/* Host-side BVH builders for hosts that do not carry the reference's Julia builder.
+ * rt_bvh_build restates build_bvh(objects) (src/BVH.jl:65-109) from the objects' bounding boxes
+ * (6 floats each): order[k] = input index stored at sorted position k; node arrays have 2n-1 slots. */
+int rt_bvh_build(int n, const float* object_bounds, int32_t* order, float* node_bounds, int32_t* node_left,
+                 int32_t* node_right, uint8_t* node_leaf);
+/* rt_bvh_build_meshes restates build_bvh(meshes::Vector{<:Mesh}) (src/mesh.jl:217-305).  indices[m] (4 x n_tri,
+ * 0-based) is permuted in place like mesh.indices; tri_ids[m] receives the original triangle id of each column;
+ * mesh_order[k] = input mesh stored at tree position k; node arrays have 4*sum(n_tri)-1 slots (unused slots
+ * keep leaf = 255). */
+int rt_bvh_build_meshes(int n_meshes, const int32_t* n_vertices, const float* const* vertices,
+                        const int32_t* n_triangles, int32_t* const* indices, int32_t* const* tri_ids,
+                        int32_t* mesh_order, float* node_bounds, int32_t* node_left, int32_t* node_right,
+                        uint8_t* node_leaf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,179 @@
+/*
+ * rt_ref.h -- CPU ORACLE for the path-tracing hot path of rafaellg79/raytracing.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  It is a plain C++ restatement of
+ * the reference's *CPU* algorithm (render -> draw! -> trace -> SceneManager/BVH hit
+ * -> primitive hit -> scatter/emit), written from the Julia sources, one function
+ * per reference function, each citing the file:line it follows.  Only tests/, the
+ * smoke check and the cpu_baseline leg of bench.py may load it.  The shipped HIP
+ * library never links, includes or calls anything in this directory.
+ *
+ * Pinning status: the reference has no tests, golden vectors or fixtures and its
+ * toolchain (Julia + CUDA.jl) is absent, so the oracle cannot be checked against an
+ * execution of the reference: sample-level parity is UNPINNED by construction (the
+ * reference never seeds its RNG).  What pins it: hand-derived known-answer tests for
+ * every formula (tests/test_oracle_kat.py) and the statistics of the two
+ * deterministic gallery images (outputs/cornell_box_*.png, cornell_smoke_box_*.png)
+ * committed as numbers under tests/golden/.
+ *
+ * Randomness: the reference draws from an unseeded task-local RNG.  The oracle and
+ * the HIP kernels both draw from the same stateless counter-based generator
+ * (pcg4d of Jarzynski & Olano, JCGT 2020) keyed by (pixel, sample, bounce, purpose,
+ * trial, seed), so that a path's random numbers do not depend on thread, GPU or
+ * traversal order.
+ *
+ * All structs below are plain C, shared layout with include/rt_amd.h (the product
+ * ABI) so one host-side flattener can feed both.
+ */
+#ifndef RT_REF_H
+#define RT_REF_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* object kinds: one per concrete Hittable of the reference */
+enum {
+    REF_SPHERE = 1,          /* src/sphere.jl:3   p = cx,cy,cz,r */
+    REF_MOVING_SPHERE = 2,   /* src/sphere.jl:12  p = c0(3),t0,c1(3),t1,r */
+    REF_XY_RECT = 3,         /* src/aarect.jl:3   p = x0,x1,y0,y1,k */
+    REF_XZ_RECT = 4,         /* src/aarect.jl:13  p = x0,x1,z0,z1,k */
+    REF_YZ_RECT = 5,         /* src/aarect.jl:23  p = y0,y1,z0,z1,k */
+    REF_BOX = 6,             /* src/box.jl:3      p = p0(3),p1(3) */
+    REF_TRANSFORM = 7,       /* src/transform.jl:3  child = object, aux = transform index */
+    REF_CONSTANT_MEDIUM = 8, /* src/constant_medium.jl:3  child = boundary, material = phase fn, p[0] = neg_inv_density */
+    REF_BVH = 9,             /* src/BVH.jl:12 nested tree (samples/cover_the_next_week.jl:75) aux = group */
+    REF_MESH = 10            /* src/mesh.jl:5     aux = mesh index */
+};
+
+/* material types, src/material.jl:3-9 */
+enum { REF_LAMBERTIAN = 1, REF_METAL = 2, REF_DIELECTRIC = 3, REF_EMISSIVE = 4, REF_ISOTROPIC = 5 };
+
+/* texture kinds, src/texture.jl:8-37 */
+enum { REF_TEX_SOLID = 0, REF_TEX_CHECKER = 1, REF_TEX_IMAGE = 2, REF_TEX_NOISE_MARBLE = 3, REF_TEX_NOISE_SCALAR = 4 };
+
+typedef struct refObject {
+    int32_t kind;
+    int32_t material; /* index into materials, -1 if none */
+    int32_t child;    /* index into objects (Transform.object / ConstantMedium.boundary), -1 if none */
+    int32_t aux;      /* transform / group / mesh index */
+    float p[12];
+} refObject;
+
+typedef struct refTransform {
+    float xform[12]; /* 3x4 column-major, src/transform.jl:65 */
+    float inv[12];
+    float bbox[6];   /* cached world AABB min(3), max(3), src/transform.jl:47-63 */
+} refTransform;
+
+typedef struct refMaterial {
+    int32_t type;
+    int32_t texture;
+    float fuzz;
+    float eta;
+} refMaterial;
+
+typedef struct refTexture {
+    int32_t kind;
+    int32_t a; /* checker: odd texture; image: image index; noise: perlin index */
+    int32_t b; /* checker: even texture */
+    int32_t pad;
+    float color[3];
+    float scale;
+} refTexture;
+
+typedef struct refImage {
+    int32_t width, height;
+    const uint8_t* rgb; /* row-major, row 0 = top, 3 bytes per texel */
+} refImage;
+
+typedef struct refPerlin {
+    float ranvec[256 * 3];
+    int32_t perm_x[256], perm_y[256], perm_z[256];
+} refPerlin;
+
+typedef struct refMesh {
+    int32_t n_vertices, n_triangles, n_materials, pad;
+    const float* vertices;    /* 8 floats per vertex: position, normal, u, v  (src/vertex.jl:3-8) */
+    const int32_t* indices;   /* 4 x n_triangles column-major: 3 vertex ids (0-based) + local material id */
+    const int32_t* materials; /* local material id -> global material index */
+    const int32_t* unused;    /* keeps the layout equal to the product ABI's mesh record */
+} refMesh;
+
+typedef struct refGroup {
+    int32_t first, count; /* slice of group_items */
+} refGroup;
+
+typedef struct refWorld {
+    int32_t n_objects;    const refObject* objects;
+    int32_t n_top;        const int32_t* top; /* the `world` vector of render(): object indices in insertion order */
+    int32_t n_transforms; const refTransform* transforms;
+    int32_t n_materials;  const refMaterial* materials;
+    int32_t n_textures;   const refTexture* textures;
+    int32_t n_images;     const refImage* images;
+    int32_t n_perlins;    const refPerlin* perlins;
+    int32_t n_meshes;     const refMesh* meshes;
+    int32_t n_groups;     const refGroup* groups;
+    const int32_t* group_items;
+} refWorld;
+
+typedef struct refCamera { /* src/camera.jl:3-14 */
+    float origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    float lens_radius, t0, t1;
+} refCamera;
+
+typedef struct refStats {
+    double seconds;
+    uint64_t paths, rays, node_visits;
+    uint64_t prim_tests[12]; /* by object kind */
+    uint64_t scatters[6];    /* by material type */
+} refStats;
+
+typedef struct ref_scene ref_scene;
+
+int ref_scene_create(const refWorld* world, ref_scene** out);
+void ref_scene_destroy(ref_scene*);
+const char* ref_last_error(void);
+
+/* src/Ray_Tracing.jl:71-100: out is 3*H*W floats in the memory order of a Julia
+ * Array{RGB{Float32}}(H,W): index ((col*H) + row)*3 + c, row 0 = top. */
+int ref_render(ref_scene*, const refCamera*, const float* pattern /*2 x n col-major*/, int n,
+               const float background[3], int width, int height, int max_depth, uint64_t seed,
+               int threads, float* out, refStats* stats);
+
+/* radiance of single paths: ids = n_paths triples (i = column, j = row from bottom, n = sample, 0-based) */
+int ref_trace_paths(ref_scene*, const refCamera*, const float* pattern, int n,
+                    const float background[3], int width, int height, int max_depth, uint64_t seed,
+                    const int32_t* ids, int n_paths, float* radiance /*3 x n_paths*/);
+
+/* closest hit of fixed rays against the whole SceneManager (src/scene_manager.jl:40-53).
+ * rays: 7 floats each (origin, direction, time).  prim_id = position in `top`, -1 on miss. */
+int ref_trace_rays(ref_scene*, const float* rays, int n, float tmin, float tmax, uint64_t seed,
+                   int32_t* prim_id, int32_t* sub_id, float* t, float* normal /*3n*/, float* uv /*2n*/,
+                   uint8_t* front);
+
+/* bucket / BVH introspection (src/scene_manager.jl:9-19, src/BVH.jl:65-109, src/mesh.jl:217-305) */
+int ref_bucket_count(ref_scene*);
+int ref_bucket_info(ref_scene*, int bucket, int32_t* n_objects, int32_t* n_node_slots, int32_t* is_mesh);
+int ref_bucket_bvh(ref_scene*, int bucket, int32_t* sorted_objects, float* bounds /*6 per slot*/,
+                   int32_t* left, int32_t* right, uint8_t* leaf, uint8_t* valid);
+/* triangle order of a mesh after the build permuted its index matrix (src/mesh.jl:237):
+ * tri_order[k] = original 0-based triangle id now stored in column k */
+int ref_mesh_order(ref_scene*, int mesh, int32_t* tri_order);
+
+/* src/MSAA_patterns.jl:25-58 */
+void ref_halton_sequence32(int n, float* out /*2 x n col-major*/);
+
+/* the shared deterministic generator and math kernels */
+void ref_pcg4d(uint32_t v[4]);
+float ref_rand01(uint32_t pixel, uint32_t sample, uint32_t counter, uint32_t seed32, int lane);
+float ref_logf(float x);
+float ref_sinf(float x);
+float ref_acosf(float x);
+float ref_atan2f(float y, float x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,825 @@
+// rt_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the path-tracing loop of
+// rafaellg79/raytracing: draw_kernel / cu_trace / cu_hit / scatter / emit
+// (src/Ray_Tracing.jl:51-69,102-139, src/cuscene_manager.jl:34-52, src/cuBVH.jl:32-67, src/hittable.jl:36-83).
+//
+// Arithmetic contract: every primitive intersection, hit completion and scatter formula is evaluated in the
+// operation order of the reference's Float32 code with IEEE add/mul/div/sqrt and NO fused multiply-add (this
+// file is compiled with -ffp-contract=off), so hit distances, primitive choices and scattered rays are
+// bit-identical to a plain CPU evaluation of the same formulas.  Only the BVH box test, which merely culls,
+// uses reciprocal multiplication, and it is widened so that it never rejects a box the exact test accepts.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device.h"
+#include "rt_kernels.h"
+
+#define INF __builtin_inff()
+
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float b) { return mk3(a.x * b, a.y * b, a.z * b); }
+__device__ __forceinline__ f3 operator*(float a, f3 b) { return mk3(a * b.x, a * b.y, a * b.z); }
+// src/vec3.jl:46: (x*x + y*y) + z*z, left to right
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// src/vec3.jl:57 with :31: a * F(1/length(a))
+__device__ __forceinline__ f3 normalize3(f3 a) { return a * (1.0f / sqrtf(dot3(a, a))); }
+__device__ __forceinline__ bool is_zero3(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+__device__ __forceinline__ f3 at3(f3 o, f3 d, float t) { return o + d * t; }
+
+// ------------------------------------------------------------------ deterministic math (same sequences as
+// the checker uses on the CPU: only IEEE basic operations, so results are reproducible bit for bit)
+__device__ __forceinline__ float det_logf(float x) {
+    if (x == 0.0f) return -INF;
+    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+    const float Lg1 = 0.66666662693f, Lg2 = 0.40000972152f, Lg3 = 0.28498786688f, Lg4 = 0.24279078841f;
+    uint32_t ix = __float_as_uint(x);
+    ix += 0x3f800000u - 0x3f3504f3u;
+    int k = (int)(ix >> 23) - 0x7f;
+    ix = (ix & 0x007fffffu) + 0x3f3504f3u;
+    float m = __uint_as_float(ix);
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float w = z * z;
+    float t1 = w * (Lg2 + w * Lg4);
+    float t2 = z * (Lg1 + w * Lg3);
+    float R = t2 + t1;
+    float hfsq = 0.5f * f * f;
+    float dk = (float)k;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+__device__ __noinline__ float det_sinf(float x) {
+    const double TWO_OVER_PI = 0.63661977236758134308;
+    const double PIO2 = 1.57079632679489661923;
+    double xd = (double)x;
+    double n = floor(xd * TWO_OVER_PI + 0.5);
+    float r = (float)(xd - n * PIO2);
+    long long q = (long long)n;
+    float z = r * r;
+    float sn, cs;
+    {
+        const float S1 = -1.6666667163e-01f, S2 = 8.3333337680e-03f, S3 = -1.9841270114e-04f,
+                    S4 = 2.7557314297e-06f, S5 = -2.5050759689e-08f, S6 = 1.5896910177e-10f;
+        float p = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+        sn = r + (r * z) * (S1 + z * p);
+    }
+    {
+        const float C1 = 4.1666667908e-02f, C2 = -1.3888889225e-03f, C3 = 2.4801587642e-05f,
+                    C4 = -2.7557314297e-07f, C5 = 2.0875723372e-09f, C6 = -1.1359647598e-11f;
+        float p = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+        cs = 1.0f - (0.5f * z - z * p);
+    }
+    switch ((int)(q & 3)) {
+        case 0: return sn;
+        case 1: return cs;
+        case 2: return -sn;
+        default: return -cs;
+    }
+}
+
+__device__ __forceinline__ double det_atan01(double z) {
+    z = z / (1.0 + sqrt(1.0 + z * z));
+    z = z / (1.0 + sqrt(1.0 + z * z));
+    double w = z * z;
+    double p = 1.0 / 17.0;
+    p = 1.0 / 15.0 - w * p;
+    p = 1.0 / 13.0 - w * p;
+    p = 1.0 / 11.0 - w * p;
+    p = 1.0 / 9.0 - w * p;
+    p = 1.0 / 7.0 - w * p;
+    p = 1.0 / 5.0 - w * p;
+    p = 1.0 / 3.0 - w * p;
+    p = 1.0 - w * p;
+    return 4.0 * (z * p);
+}
+__device__ __noinline__ double det_atan2d(double y, double x) {
+    const double PI = 3.14159265358979323846;
+    double ax = fabs(x), ay = fabs(y);
+    double a;
+    if (ax == 0.0 && ay == 0.0) a = 0.0;
+    else if (ax >= ay) a = det_atan01(ay / ax);
+    else a = 0.5 * PI - det_atan01(ax / ay);
+    if (__builtin_signbit(x)) a = PI - a;
+    if (__builtin_signbit(y)) a = -a;
+    return a;
+}
+// src/sphere.jl:104-108
+__device__ __forceinline__ void sphere_uv(f3 p, float& u, float& v) {
+    const float PI_F = 3.14159265358979323846f;
+    const float TWO_PI_F = (float)(2.0 * 3.14159265358979323846);
+    float cy = -p.y;
+    cy = cy < -1.0f ? -1.0f : (cy > 1.0f ? 1.0f : cy);
+    double cd = (double)cy;
+    float theta = (float)det_atan2d(sqrt((1.0 - cd) * (1.0 + cd)), cd);
+    float phi = (float)det_atan2d((double)(-p.z), (double)p.x) + PI_F;
+    u = phi / TWO_PI_F;
+    v = theta / PI_F;
+}
+
+// ------------------------------------------------------------------ counter-based random numbers
+// pcg4d (Jarzynski & Olano, JCGT 2020) of (pixel, sample, counter, seed); counter = bounce | purpose | index.
+struct u4 {
+    uint32_t x, y, z, w;
+};
+__device__ __forceinline__ u4 pcg4d(u4 v) {
+    v.x = v.x * 1664525u + 1013904223u;
+    v.y = v.y * 1664525u + 1013904223u;
+    v.z = v.z * 1664525u + 1013904223u;
+    v.w = v.w * 1664525u + 1013904223u;
+    v.x += v.y * v.w; v.y += v.z * v.x; v.z += v.x * v.y; v.w += v.y * v.z;
+    v.x ^= v.x >> 16; v.y ^= v.y >> 16; v.z ^= v.z >> 16; v.w ^= v.w >> 16;
+    v.x += v.y * v.w; v.y += v.z * v.x; v.z += v.x * v.y; v.w += v.y * v.z;
+    return v;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+#define PURPOSE_TRIAL 0u
+#define PURPOSE_SCALAR 1u
+#define PURPOSE_MEDIUM 2u
+#define CAMERA_BOUNCE 63u
+
+struct RngKey {
+    uint32_t pixel, sample, seed32, bounce;
+};
+__device__ __forceinline__ u4 rng_draw(const RngKey& k, uint32_t purpose, uint32_t idx) {
+    return pcg4d(u4{k.pixel, k.sample, (k.bounce << 26) | (purpose << 24) | (idx & 0xFFFFFFu), k.seed32});
+}
+// src/vec3.jl:87-94
+__device__ __forceinline__ f3 random_in_unit_sphere(const RngKey& k) {
+    for (uint32_t trial = 0;; ++trial) {
+        u4 r = rng_draw(k, PURPOSE_TRIAL, trial);
+        f3 p = mk3(u01(r.x) * 2.0f + -1.0f, u01(r.y) * 2.0f + -1.0f, u01(r.z) * 2.0f + -1.0f);
+        if (!(dot3(p, p) > 1.0f)) return p;
+    }
+}
+// src/vec3.jl:96-105
+__device__ __forceinline__ f3 random_in_unit_disk(const RngKey& k) {
+    for (uint32_t trial = 0;; ++trial) {
+        u4 r = rng_draw(k, PURPOSE_TRIAL, trial);
+        f3 p = mk3(u01(r.x) * 2.0f - 1.0f, u01(r.y) * 2.0f - 1.0f, 0.0f);
+        if (!(dot3(p, p) > 1.0f)) return p;
+    }
+}
+
+// ------------------------------------------------------------------ transforms (src/transform.jl:76-98)
+__device__ __forceinline__ f3 apply_point(const float* T, f3 v) {
+    return mk3(T[0] * v.x + T[3] * v.y + T[6] * v.z + T[9], T[1] * v.x + T[4] * v.y + T[7] * v.z + T[10],
+               T[2] * v.x + T[5] * v.y + T[8] * v.z + T[11]);
+}
+__device__ __forceinline__ f3 apply_vec(const float* T, f3 v) {
+    return mk3(T[0] * v.x + T[3] * v.y + T[6] * v.z, T[1] * v.x + T[4] * v.y + T[7] * v.z,
+               T[2] * v.x + T[5] * v.y + T[8] * v.z);
+}
+
+// ------------------------------------------------------------------ primitive tests: distance only
+struct Geom { // the 9 geometry floats of a primitive record
+    float g[9];
+};
+__device__ __forceinline__ void load_prim(const DevScene& S, uint32_t prim, uint4& head, Geom& G) {
+    const uint4* p = S.prims + 3u * prim;
+    head = p[0];
+    uint4 a = p[1], b = p[2];
+    G.g[0] = __uint_as_float(head.w);
+    G.g[1] = __uint_as_float(a.x); G.g[2] = __uint_as_float(a.y); G.g[3] = __uint_as_float(a.z); G.g[4] = __uint_as_float(a.w);
+    G.g[5] = __uint_as_float(b.x); G.g[6] = __uint_as_float(b.y); G.g[7] = __uint_as_float(b.z); G.g[8] = __uint_as_float(b.w);
+}
+
+// src/sphere.jl:45-65: the root test is done scaled by a = dot(d,d), the division comes last
+__device__ __forceinline__ float sphere_t(f3 center, float radius, f3 o, f3 d, float t_min, float t_max) {
+    f3 oc = o - center;
+    float a = dot3(d, d);
+    float half_b = dot3(oc, d);
+    float c = dot3(oc, oc) - radius * radius;
+    float disc = half_b * half_b - a * c;
+    if (disc < 0.0f) return INF;
+    float sqrtd = sqrtf(disc);
+    float root = (-half_b - sqrtd);
+    if (root < t_min * a || t_max * a < root) {
+        root = (-half_b + sqrtd);
+        if (root < t_min * a || t_max * a < root) return INF;
+    }
+    return root / a;
+}
+// src/aarect.jl:49-95; (ok,dk) constant axis, (oa,da),(ob,db) the two in-plane axes
+__device__ __forceinline__ float rect_t(float ok, float dk, float oa, float da, float ob, float db, float a0, float a1,
+                                        float b0, float b1, float k, float t_min, float t_max) {
+    float t = (k - ok) / dk;
+    if (t < t_min || t_max < t) return INF;
+    float a = oa + t * da;
+    float b = ob + t * db;
+    if (a < a0 || a1 < a || b < b0 || b1 < b) return INF;
+    return t;
+}
+// src/box.jl:9-24,43-83: six rectangles in the order front, back, top, bottom, right, left; strict <
+__device__ __forceinline__ float box_t(const float* g, f3 o, f3 d, float t_min, float t_max, uint32_t& side) {
+    float best = INF;
+    float t;
+    t = rect_t(o.z, d.z, o.x, d.x, o.y, d.y, g[0], g[3], g[1], g[4], g[5], t_min, t_max);
+    if (t < best) { best = t; side = 0; t_max = t; }
+    t = rect_t(o.z, d.z, o.x, d.x, o.y, d.y, g[0], g[3], g[1], g[4], g[2], t_min, t_max);
+    if (t < best) { best = t; side = 1; t_max = t; }
+    t = rect_t(o.y, d.y, o.x, d.x, o.z, d.z, g[0], g[3], g[2], g[5], g[4], t_min, t_max);
+    if (t < best) { best = t; side = 2; t_max = t; }
+    t = rect_t(o.y, d.y, o.x, d.x, o.z, d.z, g[0], g[3], g[2], g[5], g[1], t_min, t_max);
+    if (t < best) { best = t; side = 3; t_max = t; }
+    t = rect_t(o.x, d.x, o.y, d.y, o.z, d.z, g[1], g[4], g[2], g[5], g[3], t_min, t_max);
+    if (t < best) { best = t; side = 4; t_max = t; }
+    t = rect_t(o.x, d.x, o.y, d.y, o.z, d.z, g[1], g[4], g[2], g[5], g[0], t_min, t_max);
+    if (t < best) { best = t; side = 5; t_max = t; }
+    return best;
+}
+// src/triangle.jl:73-91
+__device__ __forceinline__ float triangle_t(const float* g, f3 o, f3 d, float t_min, float t_max, f3& normal,
+                                            float& u, float& v) {
+    f3 v1 = mk3(g[0], g[1], g[2]);
+    f3 e1 = mk3(g[3], g[4], g[5]) - v1;
+    f3 e2 = mk3(g[6], g[7], g[8]) - v1;
+    f3 origin_v1 = v1 - o;
+    normal = cross3(e1, e2);
+    f3 s = cross3(origin_v1, d);
+    float c = 1.0f / dot3(normal, d);
+    u = dot3(s, e2) * c;
+    v = dot3(s, e1) * -c;
+    float t = dot3(normal, origin_v1) * c;
+    if (u < 0.0f || v < 0.0f || u + v > 1.0f || t < t_min || t_max < t) return INF;
+    return t;
+}
+
+// distance to a simple shape (sphere, moving sphere, rectangle, box) in the ray's current frame
+__device__ __forceinline__ float shape_t(uint32_t kind, const float* g, f3 o, f3 d, float time, float t_min,
+                                         float t_max, uint32_t& side) {
+    switch (kind) {
+        case DP_SPHERE:
+            return sphere_t(mk3(g[0], g[1], g[2]), g[3], o, d, t_min, t_max);
+        case DP_MOVING_SPHERE: { // src/sphere.jl:24-26
+            f3 c0 = mk3(g[0], g[1], g[2]), c1 = mk3(g[4], g[5], g[6]);
+            f3 center = c0 + ((time - g[3]) / (g[7] - g[3])) * (c1 - c0);
+            return sphere_t(center, g[8], o, d, t_min, t_max);
+        }
+        case DP_XY_RECT:
+            return rect_t(o.z, d.z, o.x, d.x, o.y, d.y, g[0], g[1], g[2], g[3], g[4], t_min, t_max);
+        case DP_XZ_RECT:
+            return rect_t(o.y, d.y, o.x, d.x, o.z, d.z, g[0], g[1], g[2], g[3], g[4], t_min, t_max);
+        case DP_YZ_RECT:
+            return rect_t(o.x, d.x, o.y, d.y, o.z, d.z, g[0], g[1], g[2], g[3], g[4], t_min, t_max);
+        case DP_BOX:
+            return box_t(g, o, d, t_min, t_max, side);
+        default:
+            return INF;
+    }
+}
+
+// ------------------------------------------------------------------ closest hit over the whole scene
+struct Closest {
+    float t;
+    uint32_t prim; // primitive index
+    uint32_t sx;   // box side (bits 0-2) | (transform index + 1) << 3
+    uint32_t rank; // tie-break: higher wins among equal t
+};
+struct Counters {
+    uint32_t rays, nodes, prims;
+};
+
+// Traversal of the flattened SceneManager.  Equivalent to hit(::SceneManager, ray, t_min, t_max)
+// (src/scene_manager.jl:40-53) over per-type trees traversed as in src/BVH.jl:22-53 / src/mesh.jl:115-163:
+// the closest hit wins; among exactly equal distances the reference keeps the earlier type group and, inside
+// a group, the leaf its right-child-first stack order reaches first -- encoded here as `rank`.
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max,
+                                            const RngKey& key, Closest& best, Counters& cnt) {
+    best.t = INF;
+    best.prim = 0xFFFFFFFFu;
+    best.sx = 0;
+    best.rank = 0;
+    if (COUNT) cnt.rays++;
+    f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // state for one level of nesting (a BVHTree used as an object inside a Transform)
+    f3 so = o, sd = d;
+    uint32_t ret = RT_NODE_END, inst_rank = 0, inst_xf = 0;
+    uint32_t node = S.n_nodes ? 0u : RT_NODE_END;
+    for (;;) {
+        if (node >= RT_NODE_END_SUB) {
+            if (node == RT_NODE_END) break;
+            o = so; d = sd;
+            inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            node = ret;
+            inst_rank = 0; inst_xf = 0;
+            continue;
+        }
+        float4 q0 = S.nodes[2u * node], q1 = S.nodes[2u * node + 1u];
+        if (COUNT) cnt.nodes++;
+        // Box test (src/bounding_box.jl:70-84 form).  It only culls: the far distance is widened by 8 ulp so
+        // that rounding can never reject a box that the exact slab test of src/bounding_box.jl:20-67 accepts;
+        // NaNs (0 * Inf) drop out of fminf/fmaxf, which keeps the axis unconstrained.
+        float tx0 = (q0.x - o.x) * inv.x, tx1 = (q1.x - o.x) * inv.x;
+        float ty0 = (q0.y - o.y) * inv.y, ty1 = (q1.y - o.y) * inv.y;
+        float tz0 = (q0.z - o.z) * inv.z, tz1 = (q1.z - o.z) * inv.z;
+        float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t_min));
+        float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), t_max));
+        tfar = __builtin_fmaf(fabsf(tfar), 4.8e-7f, tfar);
+        uint32_t skip = __float_as_uint(q0.w);
+        uint32_t leaf = __float_as_uint(q1.w);
+        if (!(tnear <= tfar)) { node = skip; continue; }
+        if (leaf == 0u) { node = node + 1u; continue; }
+        node = skip;
+
+        uint32_t prim = leaf - 1u;
+        uint4 head;
+        Geom G;
+        load_prim(S, prim, head, G);
+        if (COUNT) cnt.prims++;
+        uint32_t kind = head.x & 15u;
+        uint32_t field = head.x >> 8;
+        if (kind == DP_INSTANCE) {
+            // Transform{BVHTree}: src/transform.jl:104-116 around src/BVH.jl:22-53
+            so = o; sd = d;
+            ret = node;
+            inst_rank = head.z;
+            inst_xf = field;
+            if (field) {
+                const float* T = S.xforms + 24u * (field - 1u) + 12;
+                f3 no = apply_point(T, o), nd = apply_vec(T, d);
+                o = no; d = nd;
+                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            }
+            node = __float_as_uint(G.g[0]);
+            continue;
+        }
+        float t;
+        uint32_t side = 0, xf = inst_xf;
+        if (kind == DP_TRIANGLE) {
+            f3 nrm;
+            float u, v;
+            t = triangle_t(G.g, o, d, t_min, t_max, nrm, u, v);
+        } else {
+            f3 ro = o, rd = d;
+            if (field) { // Transform: src/transform.jl:104-105
+                const float* T = S.xforms + 24u * (field - 1u) + 12;
+                ro = apply_point(T, o);
+                rd = apply_vec(T, d);
+                xf = field;
+            }
+            if (head.x & DP_MEDIUM_FLAG) {
+                // src/constant_medium.jl:29-65
+                uint32_t s2;
+                float t1 = shape_t(kind, G.g, ro, rd, time, -INF, INF, s2);
+                t = INF;
+                if (t1 != INF) {
+                    float t2 = shape_t(kind, G.g, ro, rd, time, t1 + 0.0001f, INF, s2);
+                    if (t2 != INF) {
+                        if (t1 < t_min) t1 = t_min;
+                        if (t2 > t_max) t2 = t_max;
+                        if (t1 < t2) {
+                            if (t1 < 0.0f) t1 = 0.0f;
+                            float ray_length = sqrtf(dot3(d, d));
+                            float distance_inside = (t2 - t1) * ray_length;
+                            u4 r = rng_draw(key, PURPOSE_MEDIUM, __float_as_uint(G.g[7]));
+                            float hit_distance = G.g[6] * det_logf(u01(r.x));
+                            if (!(hit_distance > distance_inside)) t = t1 + hit_distance / ray_length;
+                        }
+                    }
+                }
+            } else {
+                t = shape_t(kind, G.g, ro, rd, time, t_min, t_max, side);
+            }
+        }
+        uint32_t rank = head.z + inst_rank;
+        if (t < best.t || (t == best.t && t != INF && rank > best.rank)) {
+            best.t = t;
+            best.prim = prim;
+            best.sx = side | (xf << 3);
+            best.rank = rank;
+            t_max = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ hit completion (only for the winner)
+struct HitRec { // src/hit_record.jl:4-12 with the material replaced by its index
+    f3 p, n;
+    float u, v;
+    uint32_t material;
+    bool front;
+};
+
+template <bool FULL_UV>
+__device__ __forceinline__ void complete_hit(const DevScene& S, f3 o, f3 d, float time, const Closest& best,
+                                             HitRec& h) {
+    uint4 head;
+    Geom G;
+    load_prim(S, best.prim, head, G);
+    const float* g = G.g;
+    uint32_t kind = head.x & 15u;
+    uint32_t side = best.sx & 7u, xf = best.sx >> 3;
+    float t = best.t;
+    h.material = head.y;
+    if (head.x & DP_MEDIUM_FLAG) { // src/constant_medium.jl:62-64
+        h.p = at3(o, d, t);
+        h.n = mk3(1.0f, 0.0f, 0.0f);
+        h.front = false;
+        h.u = 0.0f; h.v = 0.0f;
+        return;
+    }
+    f3 ro = o, rd = d;
+    const float* T = nullptr;
+    if (xf) {
+        T = S.xforms + 24u * (xf - 1u);
+        ro = apply_point(T + 12, o);
+        rd = apply_vec(T + 12, d);
+    }
+    bool want_uv = FULL_UV || (S.materials[head.y].x & DM_NEEDS_UV);
+    h.u = 0.0f; h.v = 0.0f;
+    if (kind == DP_SPHERE || kind == DP_MOVING_SPHERE) { // src/sphere.jl:67-71
+        f3 center;
+        float radius;
+        if (kind == DP_SPHERE) { center = mk3(g[0], g[1], g[2]); radius = g[3]; }
+        else {
+            f3 c0 = mk3(g[0], g[1], g[2]), c1 = mk3(g[4], g[5], g[6]);
+            center = c0 + ((time - g[3]) / (g[7] - g[3])) * (c1 - c0);
+            radius = g[8];
+        }
+        h.p = at3(ro, rd, t);
+        f3 normal = (h.p - center) * (1.0f / radius);
+        h.front = dot3(rd, normal) < 0.0f;
+        if (want_uv) sphere_uv(normal, h.u, h.v);
+        h.n = (h.front ? 1.0f : -1.0f) * normal;
+    } else if (kind == DP_TRIANGLE) { // src/triangle.jl:101-121
+        f3 normal;
+        float u, v;
+        triangle_t(g, ro, rd, -INF, INF, normal, u, v);
+        const float* A = S.tri_attr + 16u * (head.x >> 8);
+        float w = 1.0f - u - v;
+        f3 vn = (mk3(A[0], A[1], A[2]) * w + mk3(A[3], A[4], A[5]) * u) + mk3(A[6], A[7], A[8]) * v;
+        float vu = (A[9] * w + A[11] * u) + A[13] * v;
+        float vv = (A[10] * w + A[12] * u) + A[14] * v;
+        if (is_zero3(vn)) normal = vn; // the reference's inverted "has normal data" flag (src/triangle.jl:110-113)
+        if (vu >= 0.0f && vv >= 0.0f) { u = vu; v = vv; }
+        h.p = at3(ro, rd, t);
+        h.front = dot3(rd, normal) < 0.0f;
+        h.n = (h.front ? 1.0f : -1.0f) * normalize3(normal);
+        h.u = u; h.v = v;
+    } else { // rectangles and box sides: src/aarect.jl:49-119
+        float a0, a1, b0, b1, k;
+        uint32_t axis; // constant axis: 2 = xy_rect, 1 = xz_rect, 0 = yz_rect
+        if (kind == DP_BOX) { // src/box.jl:13-22
+            switch (side) {
+                case 0: axis = 2; a0 = g[0]; a1 = g[3]; b0 = g[1]; b1 = g[4]; k = g[5]; break;
+                case 1: axis = 2; a0 = g[0]; a1 = g[3]; b0 = g[1]; b1 = g[4]; k = g[2]; break;
+                case 2: axis = 1; a0 = g[0]; a1 = g[3]; b0 = g[2]; b1 = g[5]; k = g[4]; break;
+                case 3: axis = 1; a0 = g[0]; a1 = g[3]; b0 = g[2]; b1 = g[5]; k = g[1]; break;
+                case 4: axis = 0; a0 = g[1]; a1 = g[4]; b0 = g[2]; b1 = g[5]; k = g[3]; break;
+                default: axis = 0; a0 = g[1]; a1 = g[4]; b0 = g[2]; b1 = g[5]; k = g[0]; break;
+            }
+        } else {
+            axis = kind == DP_XY_RECT ? 2u : (kind == DP_XZ_RECT ? 1u : 0u);
+            a0 = g[0]; a1 = g[1]; b0 = g[2]; b1 = g[3]; k = g[4];
+        }
+        float oa, da, ob, db, dk;
+        if (axis == 2) { oa = ro.x; da = rd.x; ob = ro.y; db = rd.y; dk = rd.z; }
+        else if (axis == 1) { oa = ro.x; da = rd.x; ob = ro.z; db = rd.z; dk = rd.y; }
+        else { oa = ro.y; da = rd.y; ob = ro.z; db = rd.z; dk = rd.x; }
+        float a = oa + t * da;
+        float b = ob + t * db;
+        // dot(direction, +axis) < 0 with the zero products kept (src/aarect.jl:98-99)
+        float dn = axis == 2 ? (rd.x * 0.0f + rd.y * 0.0f + dk * 1.0f)
+                             : (axis == 1 ? (rd.x * 0.0f + dk * 1.0f + rd.z * 0.0f) : (dk * 1.0f + rd.y * 0.0f + rd.z * 0.0f));
+        h.front = dn < 0.0f;
+        float sgn = h.front ? 1.0f : -1.0f;
+        if (axis == 2) { h.p = mk3(a, b, k); h.n = mk3(sgn * 0.0f, sgn * 0.0f, sgn * 1.0f); }
+        else if (axis == 1) { h.p = mk3(a, k, b); h.n = mk3(sgn * 0.0f, sgn * 1.0f, sgn * 0.0f); }
+        else { h.p = mk3(k, a, b); h.n = mk3(sgn * 1.0f, sgn * 0.0f, sgn * 0.0f); }
+        h.u = (a - a0) / (a1 - a0);
+        h.v = (b - b0) / (b1 - b0);
+    }
+    if (xf) { // src/transform.jl:111-115
+        h.p = at3(o, d, t);
+        h.n = apply_vec(T, h.n);
+    }
+}
+
+// ------------------------------------------------------------------ textures (src/texture.jl:42-100, src/perlin.jl)
+__device__ __noinline__ float perlin_noise(const DevScene& S, uint32_t pi, f3 p) { // src/perlin.jl:48-85
+    const float* vec = S.perlin_vec + 768u * pi;
+    const int32_t* perm = S.perlin_perm + 768u * pi;
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    float uu = u * u * (3.0f - 2.0f * u);
+    float vv = v * v * (3.0f - 2.0f * v);
+    float ww = w * w * (3.0f - 2.0f * w);
+    float accum = 0.0f;
+    for (int kk = 0; kk <= 1; ++kk)
+        for (int jj = 0; jj <= 1; ++jj)
+            for (int ii = 0; ii <= 1; ++ii) {
+                int idx = perm[(i + ii + 1) & 255] ^ perm[256 + ((j + jj + 1) & 255)] ^ perm[512 + ((k + kk + 1) & 255)];
+                f3 c = mk3(vec[3 * idx], vec[3 * idx + 1], vec[3 * idx + 2]);
+                f3 weight_v = mk3(u - (float)ii, v - (float)jj, w - (float)kk);
+                float fi = (float)ii, fj = (float)jj, fk = (float)kk;
+                accum += (fi * uu + (1.0f - fi) * (1.0f - uu)) * (fj * vv + (1.0f - fj) * (1.0f - vv)) *
+                         (fk * ww + (1.0f - fk) * (1.0f - ww)) * dot3(c, weight_v);
+            }
+    return accum;
+}
+__device__ __noinline__ float perlin_noise_scalar(const DevScene& S, uint32_t pi, f3 p) { // src/perlin.jl:87-97
+    const float* vec = S.perlin_vec + 768u * pi;
+    const int32_t* perm = S.perlin_perm + 768u * pi;
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    float accum = 0.0f;
+    for (int kk = 0; kk <= 1; ++kk)
+        for (int jj = 0; jj <= 1; ++jj)
+            for (int ii = 0; ii <= 1; ++ii) {
+                int idx = perm[(i + ii + 1) & 255] ^ perm[256 + ((j + jj + 1) & 255)] ^ perm[512 + ((k + kk + 1) & 255)];
+                float fi = (float)ii, fj = (float)jj, fk = (float)kk;
+                accum += (fi * u + (1.0f - fi) * (1.0f - u)) * (fj * v + (1.0f - fj) * (1.0f - v)) *
+                         (fk * w + (1.0f - fk) * (1.0f - w)) * vec[3 * idx];
+            }
+    return accum;
+}
+__device__ __forceinline__ float turbulence(const DevScene& S, uint32_t pi, f3 p) { // src/perlin.jl:35-46
+    float accum = 0.0f, weight = 1.0f;
+    for (int i = 0; i < 7; ++i) {
+        accum += weight * perlin_noise(S, pi, p);
+        weight *= 0.5f;
+        p = p * 2.0f;
+    }
+    return fabsf(accum);
+}
+
+__device__ __forceinline__ f3 texture_value(const DevScene& S, uint32_t ti, float u, float v, f3 p) {
+    // a checker nests two textures (src/texture.jl:46-53): resolve it iteratively
+    for (int depth = 0; depth < 8; ++depth) {
+        uint4 a = S.textures[2u * ti];
+        uint4 b = S.textures[2u * ti + 1u];
+        switch (a.x) {
+            case 0: // SolidColor
+                return mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+            case 1: { // CheckerTexture
+                float sines = det_sinf(10.0f * p.x) * det_sinf(10.0f * p.y) * det_sinf(10.0f * p.z);
+                ti = sines < 0.0f ? a.y : a.z;
+                continue;
+            }
+            case 2: { // ImageTexture, src/texture.jl:55-76
+                DevImage im = S.images[a.y];
+                if (im.width == 0 || im.height == 0) return mk3(0.0f, 1.0f, 1.0f);
+                u = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
+                v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+                v = 1.0f - v;
+                int i = (int)(v * (float)im.height);
+                int j = (int)(u * (float)im.width);
+                if (i == 0) i = 1;
+                if (j == 0) j = 1;
+                const uint8_t* px = S.image_data + im.offset + 3u * ((uint32_t)(i - 1) * im.width + (uint32_t)(j - 1));
+                return mk3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+            }
+            case 3: { // NoiseTexture{Vec3}: marble, src/texture.jl:98-100
+                float arg = __uint_as_float(b.w) * p.z + 10.0f * turbulence(S, a.y, p);
+                float val = 0.5f * (1.0f + det_sinf(arg));
+                return mk3(val, val, val);
+            }
+            default: { // NoiseTexture{F}, src/texture.jl:79-81
+                float val = 1.0f * perlin_noise_scalar(S, a.y, __uint_as_float(b.w) * p);
+                return mk3(val, val, val);
+            }
+        }
+    }
+    return mk3(0.0f, 0.0f, 0.0f);
+}
+
+// ------------------------------------------------------------------ materials (src/material.jl:23-38, src/hittable.jl:36-83)
+__device__ __forceinline__ f3 reflect3(f3 v, f3 n) { return v - (2.0f * dot3(v, n)) * n; }
+__device__ __forceinline__ f3 refract3(f3 dir, f3 n, float ratio) {
+    float cos_theta = dot3(-dir, n);
+    f3 perp = ratio * (dir + cos_theta * n);
+    f3 parallel = (-sqrtf(fabsf(1.0f - dot3(perp, perp)))) * n;
+    return perp + parallel;
+}
+__device__ __forceinline__ float schlick(float cos_theta, float eta) {
+    float k = (1.0f - eta) / (1.0f + eta);
+    float r0 = k * k;
+    float x = 1.0f - cos_theta;
+    float x2 = x * x;
+    float x5 = (x2 * x2) * x;
+    return r0 + (1.0f - r0) * x5;
+}
+
+// One path: trace(ray, scene; background, depth) of src/Ray_Tracing.jl:11-29 / :51-69
+template <bool COUNT>
+__device__ __forceinline__ f3 trace_path(const DevScene& S, f3 o, f3 d, float time, f3 background, int depth,
+                                         RngKey& key, Counters& cnt) {
+    f3 acc = mk3(1.0f, 1.0f, 1.0f);
+    f3 color = mk3(0.0f, 0.0f, 0.0f);
+    key.bounce = 0;
+    while (depth > 0) {
+        Closest best;
+        closest_hit<COUNT>(S, o, d, time, 0.001f, INF, key, best, cnt);
+        if (best.t == INF) return color + acc * background;
+        HitRec h;
+        complete_hit<false>(S, o, d, time, best, h);
+        uint4 m = S.materials[h.material];
+        uint32_t type = m.x & 0xFFu;
+        f3 att;
+        f3 emitted = mk3(0.0f, 0.0f, 0.0f);
+        f3 nd;
+        if (type == 1u) { // Lambertian
+            nd = h.n + normalize3(random_in_unit_sphere(key));
+            if (is_zero3(nd)) nd = h.n;
+            att = texture_value(S, m.y, h.u, h.v, h.p);
+        } else if (type == 2u) { // Metal
+            f3 reflected = reflect3(normalize3(d), h.n);
+            nd = reflected + __uint_as_float(m.z) * random_in_unit_sphere(key);
+            att = dot3(nd, h.n) > 0.0f ? texture_value(S, m.y, h.u, h.v, h.p) : mk3(0.0f, 0.0f, 0.0f);
+        } else if (type == 3u) { // Dielectric
+            float eta = __uint_as_float(m.w);
+            float ratio = h.front ? (1.0f / eta) : eta;
+            f3 unit_dir = normalize3(d);
+            float cos_theta = fminf(dot3(-unit_dir, h.n), 1.0f);
+            float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+            bool refl = ratio * sin_theta > 1.0f;
+            if (!refl) refl = schlick(cos_theta, eta) > u01(rng_draw(key, PURPOSE_SCALAR, 0).x);
+            nd = refl ? reflect3(unit_dir, h.n) : refract3(unit_dir, h.n, ratio);
+            att = mk3(1.0f, 1.0f, 1.0f);
+        } else if (type == 5u) { // Isotropic
+            nd = random_in_unit_sphere(key);
+            att = texture_value(S, m.y, h.u, h.v, h.p);
+        } else { // Emissive: zero ray, zero attenuation (src/hittable.jl:72-74), emits on both faces (:77-83)
+            nd = mk3(0.0f, 0.0f, 0.0f);
+            att = mk3(0.0f, 0.0f, 0.0f);
+            emitted = texture_value(S, m.y, h.u, h.v, h.p);
+        }
+        color = color + acc * emitted;
+        if (is_zero3(att)) return color;
+        acc = acc * att;
+        o = h.p;
+        d = nd;
+        depth -= 1;
+        key.bounce += 1;
+    }
+    return color;
+}
+
+// get_ray (src/camera.jl:38-42) for pixel column i, row j (from the bottom), pattern column n
+__device__ __forceinline__ void camera_ray(const RtCameraDev& cam, const float* pattern, int i, int j, int n, int width,
+                                           int height, RngKey& key, f3& o, f3& d, float& time) {
+    float dx = pattern[2 * n], dy = pattern[2 * n + 1];
+    float s = ((float)i + dx) / (float)(width - 1); // src/Ray_Tracing.jl:85-86
+    float t = ((float)j + dy) / (float)(height - 1);
+    key.bounce = CAMERA_BOUNCE;
+    f3 cu = mk3(cam.u[0], cam.u[1], cam.u[2]), cv = mk3(cam.v[0], cam.v[1], cam.v[2]);
+    f3 origin = mk3(cam.origin[0], cam.origin[1], cam.origin[2]);
+    f3 llc = mk3(cam.llc[0], cam.llc[1], cam.llc[2]);
+    f3 hor = mk3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
+    f3 ver = mk3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
+    f3 rd = cam.lens_radius * random_in_unit_disk(key);
+    o = (cu * rd.x + cv * rd.y) + origin;
+    time = u01(rng_draw(key, PURPOSE_SCALAR, 0).x) * (cam.t1 - cam.t0) + cam.t0;
+    d = ((llc + s * hor) + t * ver) - o;
+}
+
+// ------------------------------------------------------------------ kernels
+// Work decomposition: the image is cut into 8x8-pixel tiles, one wave per (tile, chunk); lane l owns pixel
+// (l & 7, l >> 3) of the tile and sums its chunk's pattern columns in order.  Chunks exist only to expose more
+// waves than pixels/64; partial sums go to partial[chunk][pixel] and are added up in chunk order by
+// rt_reduce_kernel, so the result does not depend on scheduling.
+template <bool COUNT>
+__global__ void __launch_bounds__(256) rt_render_kernel(DevScene S, RtCameraDev cam, const float* __restrict__ pattern,
+                                                        RtRenderParams P, float* __restrict__ partial,
+                                                        unsigned long long* __restrict__ counters) {
+    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t lane = threadIdx.x & 63u;
+    uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    uint32_t chunk = wave / n_tiles;
+    uint32_t tile = wave - chunk * n_tiles;
+    if (chunk >= P.n_chunks) return;
+    int i = (int)((tile % P.tiles_x) * 8u + (lane & 7u));
+    int j = (int)((tile / P.tiles_x) * 8u + (lane >> 3));
+    if (i >= P.width || j >= P.height) return;
+    Counters cnt = {0, 0, 0};
+    RngKey key;
+    key.pixel = (uint32_t)j * (uint32_t)P.width + (uint32_t)i;
+    key.seed32 = P.seed32;
+    f3 bg = mk3(P.background[0], P.background[1], P.background[2]);
+    f3 col = mk3(0.0f, 0.0f, 0.0f);
+    // shard sample k is pattern column sample_first + k*sample_stride; this chunk takes k = chunk, chunk + n_chunks, ...
+    for (uint32_t k = chunk; k < P.n_shard_samples; k += P.n_chunks) {
+        int n = P.sample_first + (int)k * P.sample_stride;
+        key.sample = (uint32_t)n;
+        f3 o, d;
+        float time;
+        camera_ray(cam, pattern, i, j, n, P.width, P.height, key, o, d, time);
+        col = col + trace_path<COUNT>(S, o, d, time, bg, P.max_depth, key, cnt);
+    }
+    size_t idx = ((size_t)i * (size_t)P.height + (size_t)(P.height - 1 - j)) * 3u; // img[height-j, i+1]
+    float* dst = partial + (size_t)chunk * P.image_floats + idx;
+    dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
+    if (COUNT) {
+        atomicAdd(&counters[0], (unsigned long long)cnt.rays);
+        atomicAdd(&counters[1], (unsigned long long)cnt.nodes);
+        atomicAdd(&counters[2], (unsigned long long)cnt.prims);
+    }
+}
+
+// accum[i] = sum over chunks, in chunk order
+__global__ void __launch_bounds__(256) rt_reduce_kernel(const float* __restrict__ partial, uint32_t n_chunks,
+                                                        size_t image_floats, float* __restrict__ accum) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= image_floats) return;
+    float s = partial[i];
+    for (uint32_t c = 1; c < n_chunks; ++c) s = s + partial[(size_t)c * image_floats + i];
+    accum[i] = s;
+}
+
+// col /= N; sqrt per channel (src/Ray_Tracing.jl:90-91,152-153; the division is a multiply by Float32(1/N))
+__global__ void __launch_bounds__(256) rt_finalize_kernel(const float* __restrict__ accum, float inv_n,
+                                                          size_t image_floats, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= image_floats) return;
+    out[i] = sqrtf(accum[i] * inv_n);
+}
+
+__global__ void __launch_bounds__(256) rt_trace_rays_kernel(DevScene S, const float* __restrict__ rays, int n, float t_min,
+                                                            float t_max, uint32_t seed32, int32_t* prim_id,
+                                                            int32_t* sub_id, float* t_out, float* normal, float* uv,
+                                                            uint8_t* front) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float* q = rays + 7 * (size_t)k;
+    f3 o = mk3(q[0], q[1], q[2]), d = mk3(q[3], q[4], q[5]);
+    float time = q[6];
+    RngKey key = {(uint32_t)k, 0u, seed32, 0u};
+    Counters cnt = {0, 0, 0};
+    Closest best;
+    closest_hit<false>(S, o, d, time, t_min, t_max, key, best, cnt);
+    HitRec h;
+    h.p = mk3(INF, INF, INF); h.n = mk3(0, 0, 0); h.u = 0; h.v = 0; h.front = false; h.material = 0;
+    int pid = -1, sid = -1;
+    if (best.t != INF) {
+        complete_hit<true>(S, o, d, time, best, h);
+        pid = S.prim_top[best.prim];
+        uint4 head = S.prims[3u * best.prim];
+        sid = S.prim_sub[best.prim] + (((head.x & 15u) == DP_BOX) ? (int)(best.sx & 7u) : 0);
+    }
+    prim_id[k] = pid;
+    sub_id[k] = sid;
+    t_out[k] = best.t;
+    normal[3 * k] = h.n.x; normal[3 * k + 1] = h.n.y; normal[3 * k + 2] = h.n.z;
+    uv[2 * k] = h.u; uv[2 * k + 1] = h.v;
+    front[k] = h.front ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) rt_trace_paths_kernel(DevScene S, RtCameraDev cam, const float* __restrict__ pattern,
+                                                             RtRenderParams P, const int32_t* __restrict__ ids,
+                                                             int n_paths, float* __restrict__ radiance) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_paths) return;
+    int i = ids[3 * k], j = ids[3 * k + 1], n = ids[3 * k + 2];
+    RngKey key;
+    key.pixel = (uint32_t)j * (uint32_t)P.width + (uint32_t)i;
+    key.sample = (uint32_t)n;
+    key.seed32 = P.seed32;
+    Counters cnt = {0, 0, 0};
+    f3 o, d;
+    float time;
+    camera_ray(cam, pattern, i, j, n, P.width, P.height, key, o, d, time);
+    f3 c = trace_path<false>(S, o, d, time, mk3(P.background[0], P.background[1], P.background[2]), P.max_depth, key, cnt);
+    radiance[3 * k] = c.x; radiance[3 * k + 1] = c.y; radiance[3 * k + 2] = c.z;
+}
+
+// ------------------------------------------------------------------ host-callable launchers
+extern "C" void rt_launch_render(const DevScene* S, const RtCameraDev* cam, const float* d_pattern, const RtRenderParams* P,
+                                 float* d_partial, unsigned long long* d_counters, bool count, hipStream_t stream) {
+    uint32_t waves = P->tiles_x * P->tiles_y * P->n_chunks;
+    uint32_t blocks = (waves + 3u) / 4u;
+    if (count) hipLaunchKernelGGL(rt_render_kernel<true>, dim3(blocks), dim3(256), 0, stream, *S, *cam, d_pattern, *P, d_partial, d_counters);
+    else hipLaunchKernelGGL(rt_render_kernel<false>, dim3(blocks), dim3(256), 0, stream, *S, *cam, d_pattern, *P, d_partial, d_counters);
+}
+extern "C" void rt_launch_reduce(const float* d_partial, uint32_t n_chunks, size_t image_floats, float* d_accum, hipStream_t stream) {
+    uint32_t blocks = (uint32_t)((image_floats + 255) / 256);
+    hipLaunchKernelGGL(rt_reduce_kernel, dim3(blocks), dim3(256), 0, stream, d_partial, n_chunks, image_floats, d_accum);
+}
+extern "C" void rt_launch_finalize(const float* d_accum, float inv_n, size_t image_floats, float* d_out, hipStream_t stream) {
+    uint32_t blocks = (uint32_t)((image_floats + 255) / 256);
+    hipLaunchKernelGGL(rt_finalize_kernel, dim3(blocks), dim3(256), 0, stream, d_accum, inv_n, image_floats, d_out);
+}
+extern "C" void rt_launch_trace_rays(const DevScene* S, const float* d_rays, int n, float t_min, float t_max, uint32_t seed32,
+                                     int32_t* prim_id, int32_t* sub_id, float* t, float* normal, float* uv, uint8_t* front,
+                                     hipStream_t stream) {
+    hipLaunchKernelGGL(rt_trace_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, *S, d_rays, n, t_min, t_max, seed32,
+                       prim_id, sub_id, t, normal, uv, front);
+}
+extern "C" void rt_launch_trace_paths(const DevScene* S, const RtCameraDev* cam, const float* d_pattern, const RtRenderParams* P,
+                                      const int32_t* d_ids, int n_paths, float* d_radiance, hipStream_t stream) {
+    hipLaunchKernelGGL(rt_trace_paths_kernel, dim3((n_paths + 255) / 256), dim3(256), 0, stream, *S, *cam, d_pattern, *P, d_ids,
+                       n_paths, d_radiance);
+}

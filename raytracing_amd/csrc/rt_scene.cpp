@@ -1,0 +1,364 @@
+// rt_scene.cpp -- turns the host's scene description (include/rt_amd.h: per-type trees as build_bvh left them,
+// object / transform / material / texture tables) into the device layout of rt_device.h.  This is the job that
+// cu(::BVHTree), CuSceneManager and the Adapt rules do in the reference (src/cuBVH.jl:20-22,
+// src/cuscene_manager.jl:16-19, src/mesh.jl:24-43, src/transform.jl:12-15, src/constant_medium.jl:12-16).
+#include "rt_scene.h"
+
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "rt_internal.h"
+
+namespace {
+
+inline uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline float bitsf(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+struct Builder {
+    const rtSceneDesc& D;
+    HostScene& H;
+    std::string err;
+    int status = RT_OK;
+
+    std::vector<float4> sub_nodes;            // nested trees, relative indices
+    std::vector<int64_t> group_root;          // per group: relative root index in sub_nodes, -1 = not emitted
+    std::vector<uint32_t> instance_prims;     // prims whose g0 holds a relative sub-tree root
+    std::map<std::vector<uint32_t>, uint32_t> xform_index; // identical matrices share one device record
+    std::vector<int> top_pos;                 // object index -> position in `top`
+    size_t visited = 0;
+
+    explicit Builder(const rtSceneDesc& d, HostScene& h) : D(d), H(h) {}
+
+    bool fail(int st, const std::string& m) {
+        if (status == RT_OK) { status = st; err = m; }
+        return false;
+    }
+
+    // ---------------------------------------------------------------- tables
+    bool needs_uv(int ti, int depth = 0) {
+        if (ti < 0 || ti >= D.n_textures || depth > 8) return false;
+        const rtTexture& t = D.textures[ti];
+        if (t.kind == RT_TEX_IMAGE) return true;
+        if (t.kind == RT_TEX_CHECKER) return needs_uv(t.a, depth + 1) || needs_uv(t.b, depth + 1);
+        return false;
+    }
+
+    bool tables() {
+        for (int i = 0; i < D.n_textures; ++i) {
+            const rtTexture& t = D.textures[i];
+            switch (t.kind) {
+                case RT_TEX_SOLID: break;
+                case RT_TEX_CHECKER:
+                    if (t.a < 0 || t.a >= D.n_textures || t.b < 0 || t.b >= D.n_textures) return fail(RT_EINVAL, "checker texture index out of range");
+                    break;
+                case RT_TEX_IMAGE:
+                    if (t.a < 0 || t.a >= D.n_images) return fail(RT_EINVAL, "image index out of range");
+                    break;
+                case RT_TEX_NOISE_MARBLE:
+                case RT_TEX_NOISE_SCALAR:
+                    if (t.a < 0 || t.a >= D.n_perlins) return fail(RT_EINVAL, "perlin index out of range");
+                    break;
+                default: return fail(RT_EUNSUPPORTED, "unknown texture kind");
+            }
+            H.textures.push_back(make_uint4((uint32_t)t.kind, (uint32_t)t.a, (uint32_t)t.b, 0u));
+            H.textures.push_back(make_uint4(fbits(t.color[0]), fbits(t.color[1]), fbits(t.color[2]), fbits(t.scale)));
+        }
+        for (int i = 0; i < D.n_materials; ++i) {
+            const rtMaterial& m = D.materials[i];
+            if (m.type < RT_LAMBERTIAN || m.type > RT_ISOTROPIC) return fail(RT_EUNSUPPORTED, "unknown material type");
+            if (m.texture < 0 || m.texture >= D.n_textures) return fail(RT_EINVAL, "material texture index out of range");
+            uint32_t flags = needs_uv(m.texture) ? DM_NEEDS_UV : 0u;
+            H.materials.push_back(make_uint4((uint32_t)m.type | flags, (uint32_t)m.texture, fbits(m.fuzz), fbits(m.eta)));
+        }
+        for (int i = 0; i < D.n_images; ++i) {
+            const rtImage& im = D.images[i];
+            if (im.width < 0 || im.height < 0 || (im.width > 0 && im.height > 0 && !im.rgb)) return fail(RT_EINVAL, "bad image");
+            DevImage d{(uint32_t)H.image_data.size(), (uint32_t)im.width, (uint32_t)im.height, 0u};
+            size_t bytes = (size_t)3 * im.width * im.height;
+            if (bytes) H.image_data.insert(H.image_data.end(), im.rgb, im.rgb + bytes);
+            while (H.image_data.size() & 3u) H.image_data.push_back(0);
+            H.images.push_back(d);
+        }
+        for (int i = 0; i < D.n_perlins; ++i) {
+            const rtPerlin& p = D.perlins[i];
+            H.perlin_vec.insert(H.perlin_vec.end(), p.ranvec, p.ranvec + 768);
+            for (int k = 0; k < 256; ++k) if (p.perm_x[k] < 0 || p.perm_x[k] > 255 || p.perm_y[k] < 0 || p.perm_y[k] > 255 || p.perm_z[k] < 0 || p.perm_z[k] > 255)
+                return fail(RT_EINVAL, "perlin permutation entry outside 0..255");
+            H.perlin_perm.insert(H.perlin_perm.end(), p.perm_x, p.perm_x + 256);
+            H.perlin_perm.insert(H.perlin_perm.end(), p.perm_y, p.perm_y + 256);
+            H.perlin_perm.insert(H.perlin_perm.end(), p.perm_z, p.perm_z + 256);
+        }
+        return true;
+    }
+
+    uint32_t xform(int ti) {
+        const rtTransform& t = D.transforms[ti];
+        std::vector<uint32_t> key(24);
+        for (int k = 0; k < 12; ++k) { key[k] = fbits(t.xform[k]); key[12 + k] = fbits(t.inv_xform[k]); }
+        auto it = xform_index.find(key);
+        if (it != xform_index.end()) return it->second;
+        uint32_t idx = (uint32_t)(H.xforms.size() / 24);
+        H.xforms.insert(H.xforms.end(), t.xform, t.xform + 12);
+        H.xforms.insert(H.xforms.end(), t.inv_xform, t.inv_xform + 12);
+        xform_index[key] = idx;
+        return idx;
+    }
+
+    // ---------------------------------------------------------------- primitives
+    uint32_t push_prim(uint32_t head, uint32_t material, uint32_t rank, const float g[9], int top, int sub) {
+        uint32_t idx = (uint32_t)(H.prims.size() / 3);
+        H.prims.push_back(make_uint4(head, material, rank, fbits(g[0])));
+        H.prims.push_back(make_uint4(fbits(g[1]), fbits(g[2]), fbits(g[3]), fbits(g[4])));
+        H.prims.push_back(make_uint4(fbits(g[5]), fbits(g[6]), fbits(g[7]), fbits(g[8])));
+        H.prim_top.push_back(top);
+        H.prim_sub.push_back(sub);
+        return idx;
+    }
+
+    bool valid_obj(int oi) { return oi >= 0 && oi < D.n_objects; }
+
+    // number of tie-break ranks an object occupies
+    uint32_t flat_count(int oi) {
+        if (!valid_obj(oi)) return 1;
+        const rtObject* o = &D.objects[oi];
+        if (o->kind == RT_TRANSFORM && valid_obj(o->child)) o = &D.objects[o->child];
+        if (o->kind == RT_BVH && o->aux >= 0 && o->aux < D.n_groups) return (uint32_t)D.groups[o->aux].n_objects;
+        if (o->kind == RT_MESH && o->aux >= 0 && o->aux < D.n_meshes) return (uint32_t)D.meshes[o->aux].n_triangles;
+        return 1;
+    }
+
+    // Object (possibly wrapped: ConstantMedium{Transform{shape}}) -> one device primitive.  Returns false on error.
+    bool make_prim(int oi, uint32_t rank, int top, int sub, bool nested, uint32_t& out) {
+        if (!valid_obj(oi)) return fail(RT_EINVAL, "object index out of range");
+        const rtObject* o = &D.objects[oi];
+        bool medium = false;
+        float neg_inv_density = 0.0f;
+        int material = -1, medium_oi = -1;
+        uint32_t xf = 0;
+        if (o->kind == RT_CONSTANT_MEDIUM) {
+            if (nested) return fail(RT_EUNSUPPORTED, "ConstantMedium inside a nested BVHTree is not supported");
+            medium = true;
+            neg_inv_density = o->p[0];
+            material = o->material;
+            medium_oi = oi;
+            if (!valid_obj(o->child)) return fail(RT_EINVAL, "ConstantMedium boundary index out of range");
+            o = &D.objects[o->child];
+        }
+        if (o->kind == RT_TRANSFORM) {
+            if (o->aux < 0 || o->aux >= D.n_transforms) return fail(RT_EINVAL, "transform index out of range");
+            if (nested) return fail(RT_EUNSUPPORTED, "Transform inside a nested BVHTree is not supported");
+            xf = xform(o->aux) + 1u;
+            if (!valid_obj(o->child)) return fail(RT_EINVAL, "Transform child index out of range");
+            o = &D.objects[o->child];
+        }
+        float g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t kind;
+        switch (o->kind) {
+            case RT_SPHERE: kind = DP_SPHERE; std::memcpy(g, o->p, 4 * sizeof(float)); break;
+            case RT_MOVING_SPHERE: kind = DP_MOVING_SPHERE; std::memcpy(g, o->p, 9 * sizeof(float)); break;
+            case RT_XY_RECT: kind = DP_XY_RECT; std::memcpy(g, o->p, 5 * sizeof(float)); break;
+            case RT_XZ_RECT: kind = DP_XZ_RECT; std::memcpy(g, o->p, 5 * sizeof(float)); break;
+            case RT_YZ_RECT: kind = DP_YZ_RECT; std::memcpy(g, o->p, 5 * sizeof(float)); break;
+            case RT_BOX: kind = DP_BOX; std::memcpy(g, o->p, 6 * sizeof(float)); break;
+            case RT_BVH: {
+                if (medium) return fail(RT_EUNSUPPORTED, "ConstantMedium with a BVHTree boundary is not supported");
+                if (nested) return fail(RT_EUNSUPPORTED, "BVHTree inside a nested BVHTree is not supported");
+                if (o->aux < 0 || o->aux >= D.n_groups) return fail(RT_EINVAL, "group index out of range");
+                int64_t root;
+                if (!emit_group(o->aux, top, root)) return false;
+                g[0] = bitsf((uint32_t)root);
+                out = push_prim(DP_INSTANCE | (xf << 8), 0u, rank, g, top, 0);
+                instance_prims.push_back(out);
+                return true;
+            }
+            case RT_MESH: return fail(RT_EUNSUPPORTED, "a Mesh is only supported as a top-level object");
+            default: return fail(RT_EUNSUPPORTED, "unsupported nesting of Transform / ConstantMedium");
+        }
+        if (medium) {
+            if (kind != DP_SPHERE && kind != DP_BOX) return fail(RT_EUNSUPPORTED, "ConstantMedium boundary must be a Sphere or a Box (optionally inside a Transform)");
+            g[6] = neg_inv_density;
+            g[7] = bitsf((uint32_t)medium_oi);
+        } else {
+            material = o->material;
+        }
+        if (material < 0 || material >= D.n_materials) return fail(RT_EINVAL, "material index out of range");
+        out = push_prim(kind | (medium ? DP_MEDIUM_FLAG : 0u) | (xf << 8), (uint32_t)material, rank, g, top, sub);
+        return true;
+    }
+
+    // ---------------------------------------------------------------- trees
+    static void push_node(std::vector<float4>& nodes, const float* b) {
+        nodes.push_back(make_float4(b[0], b[1], b[2], 0.0f));
+        nodes.push_back(make_float4(b[3], b[4], b[5], 0.0f));
+    }
+    static void set_skip(std::vector<float4>& nodes, size_t idx) { nodes[2 * idx].w = bitsf((uint32_t)(nodes.size() / 2)); }
+    static void set_leaf(std::vector<float4>& nodes, size_t idx, uint32_t prim) { nodes[2 * idx + 1].w = bitsf(prim + 1u); }
+
+    bool check_node(const rtBvh& T, int id, int depth) {
+        if (id < 1 || id > T.n_nodes) return fail(RT_EINVAL, "BVH node id out of range");
+        if (depth > 512) return fail(RT_EINVAL, "BVH deeper than 512 levels");
+        if (++visited > (size_t)4 * (size_t)(T.n_nodes + 1) + 1024) return fail(RT_EINVAL, "BVH links form a cycle");
+        return true;
+    }
+
+    // generic tree (src/BVH.jl): pre-order, left child first
+    bool emit_generic(const rtBvh& T, int id, int depth, std::vector<float4>& nodes, uint32_t rank_base,
+                      const std::vector<uint32_t>* rank_offset, bool nested, int nested_top) {
+        if (!check_node(T, id, depth)) return false;
+        size_t idx = nodes.size() / 2;
+        push_node(nodes, T.node_bounds + 6 * (size_t)(id - 1));
+        if (T.node_leaf[id - 1]) {
+            int l = T.node_left[id - 1], r = T.node_right[id - 1];
+            if (l != r || l < 1 || l > T.n_objects) return fail(RT_EINVAL, "BVH leaf must reference exactly one object");
+            int oi = T.objects[l - 1];
+            uint32_t rank = rank_base + (rank_offset ? (*rank_offset)[(size_t)(l - 1)] : (uint32_t)(l - 1));
+            int top = nested ? nested_top : (valid_obj(oi) ? top_pos[(size_t)oi] : -1);
+            uint32_t prim;
+            if (!make_prim(oi, rank, top, nested ? oi : 0, nested, prim)) return false;
+            set_leaf(nodes, idx, prim);
+        } else {
+            if (!emit_generic(T, T.node_left[id - 1], depth + 1, nodes, rank_base, rank_offset, nested, nested_top)) return false;
+            if (!emit_generic(T, T.node_right[id - 1], depth + 1, nodes, rank_base, rank_offset, nested, nested_top)) return false;
+        }
+        set_skip(nodes, idx);
+        return true;
+    }
+
+    bool emit_group(int gi, int top, int64_t& root) {
+        if (group_root[(size_t)gi] >= 0) { root = group_root[(size_t)gi]; return true; }
+        const rtBvh& T = D.groups[gi];
+        if (T.kind != 0) return fail(RT_EUNSUPPORTED, "nested tree of meshes is not supported");
+        if (T.n_objects <= 0 || T.n_nodes <= 0) return fail(RT_EINVAL, "empty nested tree");
+        size_t start = sub_nodes.size() / 2;
+        if (!emit_generic(T, 1, 0, sub_nodes, 0u, nullptr, true, top)) return false;
+        size_t end = sub_nodes.size() / 2;
+        for (size_t i = start; i < end; ++i)
+            if (fbits(sub_nodes[2 * i].w) == (uint32_t)end) sub_nodes[2 * i].w = bitsf(RT_NODE_END_SUB);
+        group_root[(size_t)gi] = (int64_t)start;
+        root = (int64_t)start;
+        return true;
+    }
+
+    // tree over meshes (src/mesh.jl:250-283): the mesh-level leaf becomes an interior node above its triangle tree
+    bool emit_tris(const rtBvh& T, const rtMesh& M, int top, int id, int depth, uint32_t rank_base) {
+        if (!check_node(T, id, depth)) return false;
+        const float* box = T.node_bounds + 6 * (size_t)(id - 1);
+        if (T.node_leaf[id - 1] == 1) {
+            int l = T.node_left[id - 1], r = T.node_right[id - 1];
+            if (l < 1 || r > M.n_triangles || l > r) return fail(RT_EINVAL, "triangle range out of bounds");
+            for (int c = l; c <= r; ++c) {
+                const int32_t* ix = M.indices + 4 * (size_t)(c - 1);
+                for (int k = 0; k < 3; ++k) if (ix[k] < 0 || ix[k] >= M.n_vertices) return fail(RT_EINVAL, "vertex index out of range");
+                if (ix[3] < 0 || ix[3] >= M.n_materials) return fail(RT_EINVAL, "mesh material id out of range");
+                int material = M.materials[ix[3]];
+                if (material < 0 || material >= D.n_materials) return fail(RT_EINVAL, "material index out of range");
+                float g[9];
+                uint32_t attr = (uint32_t)(H.tri_attr.size() / 16);
+                float a[16] = {0};
+                for (int k = 0; k < 3; ++k) {
+                    const float* v = M.vertices + 8 * (size_t)ix[k];
+                    g[3 * k] = v[0]; g[3 * k + 1] = v[1]; g[3 * k + 2] = v[2];
+                    a[3 * k] = v[3]; a[3 * k + 1] = v[4]; a[3 * k + 2] = v[5];
+                    a[9 + 2 * k] = v[6]; a[10 + 2 * k] = v[7];
+                }
+                H.tri_attr.insert(H.tri_attr.end(), a, a + 16);
+                size_t idx = H.nodes.size() / 2;
+                push_node(H.nodes, box);
+                uint32_t prim = push_prim(DP_TRIANGLE | (attr << 8), (uint32_t)material, rank_base + (uint32_t)(c - 1), g, top,
+                                          M.tri_ids ? M.tri_ids[c - 1] : c - 1);
+                set_leaf(H.nodes, idx, prim);
+                set_skip(H.nodes, idx);
+            }
+            return true;
+        }
+        if (T.node_leaf[id - 1] != 0) return fail(RT_EINVAL, "reached an unused BVH node slot");
+        size_t idx = H.nodes.size() / 2;
+        push_node(H.nodes, box);
+        if (!emit_tris(T, M, top, T.node_left[id - 1], depth + 1, rank_base)) return false;
+        if (!emit_tris(T, M, top, T.node_right[id - 1], depth + 1, rank_base)) return false;
+        set_skip(H.nodes, idx);
+        return true;
+    }
+    bool emit_mesh_level(const rtBvh& T, int id, int depth, uint32_t rank_base, const std::vector<uint32_t>& rank_offset) {
+        if (!check_node(T, id, depth)) return false;
+        if (T.node_leaf[id - 1] > 1) return fail(RT_EINVAL, "reached an unused BVH node slot");
+        size_t idx = H.nodes.size() / 2;
+        push_node(H.nodes, T.node_bounds + 6 * (size_t)(id - 1));
+        if (T.node_leaf[id - 1]) {
+            int pos = T.node_right[id - 1];
+            if (pos < 1 || pos > T.n_objects) return fail(RT_EINVAL, "mesh position out of range");
+            int oi = T.objects[pos - 1];
+            if (!valid_obj(oi) || D.objects[oi].kind != RT_MESH) return fail(RT_EINVAL, "mesh tree over a non-mesh object");
+            int mi = D.objects[oi].aux;
+            if (mi < 0 || mi >= D.n_meshes) return fail(RT_EINVAL, "mesh index out of range");
+            if (!emit_tris(T, D.meshes[mi], top_pos[(size_t)oi], T.node_left[id - 1], depth + 1, rank_base + rank_offset[(size_t)(pos - 1)])) return false;
+        } else {
+            if (!emit_mesh_level(T, T.node_left[id - 1], depth + 1, rank_base, rank_offset)) return false;
+            if (!emit_mesh_level(T, T.node_right[id - 1], depth + 1, rank_base, rank_offset)) return false;
+        }
+        set_skip(H.nodes, idx);
+        return true;
+    }
+
+    bool run() {
+        if (D.n_objects < 0 || D.n_top < 0 || D.n_buckets < 0) return fail(RT_EINVAL, "negative count");
+        if (D.n_buckets == 0) return fail(RT_EINVAL, "scene has no objects");
+        if (!tables()) return false;
+        top_pos.assign((size_t)D.n_objects, -1);
+        for (int i = 0; i < D.n_top; ++i) {
+            if (!valid_obj(D.top[i])) return fail(RT_EINVAL, "top-level object index out of range");
+            top_pos[(size_t)D.top[i]] = i;
+        }
+        group_root.assign((size_t)D.n_groups, -1);
+        // tie-break ranks: earlier type group wins, inside a group the later tree position wins
+        std::vector<std::vector<uint32_t>> offsets((size_t)D.n_buckets);
+        std::vector<uint32_t> totals((size_t)D.n_buckets, 0);
+        for (int b = 0; b < D.n_buckets; ++b) {
+            const rtBvh& T = D.buckets[b];
+            if (T.n_objects <= 0 || T.n_nodes <= 0 || !T.objects || !T.node_bounds || !T.node_left || !T.node_right || !T.node_leaf)
+                return fail(RT_EINVAL, "empty or incomplete tree record");
+            uint32_t acc = 0;
+            for (int k = 0; k < T.n_objects; ++k) {
+                offsets[(size_t)b].push_back(acc);
+                acc += flat_count(T.objects[k]);
+            }
+            totals[(size_t)b] = acc;
+        }
+        std::vector<uint32_t> base((size_t)D.n_buckets, 0);
+        for (int b = D.n_buckets - 2; b >= 0; --b) base[(size_t)b] = base[(size_t)b + 1] + totals[(size_t)b + 1];
+        for (int b = 0; b < D.n_buckets; ++b) {
+            const rtBvh& T = D.buckets[b];
+            visited = 0;
+            bool ok = T.kind == 1 ? emit_mesh_level(T, 1, 0, base[(size_t)b], offsets[(size_t)b])
+                                  : emit_generic(T, 1, 0, H.nodes, base[(size_t)b], &offsets[(size_t)b], false, -1);
+            if (!ok) return false;
+        }
+        // close the main region and append the nested trees behind it
+        uint32_t main_count = (uint32_t)(H.nodes.size() / 2);
+        for (uint32_t i = 0; i < main_count; ++i)
+            if (fbits(H.nodes[2 * (size_t)i].w) == main_count) H.nodes[2 * (size_t)i].w = bitsf(RT_NODE_END);
+        for (size_t i = 0; i < sub_nodes.size() / 2; ++i) {
+            uint32_t s = fbits(sub_nodes[2 * i].w);
+            if (s != RT_NODE_END_SUB) sub_nodes[2 * i].w = bitsf(s + main_count);
+        }
+        H.nodes.insert(H.nodes.end(), sub_nodes.begin(), sub_nodes.end());
+        for (uint32_t p : instance_prims) H.prims[3 * (size_t)p].w += main_count; // g0 holds the root as raw bits
+        if (H.nodes.size() / 2 >= RT_NODE_END_SUB) return fail(RT_EUNSUPPORTED, "too many BVH nodes");
+        return true;
+    }
+};
+
+} // namespace
+
+int rt_flatten_scene(const rtSceneDesc* desc, HostScene* out) {
+    if (!desc || !out) return rt_fail(RT_EINVAL, "rt_flatten_scene: null argument");
+    if ((desc->n_objects && !desc->objects) || (desc->n_top && !desc->top) || (desc->n_buckets && !desc->buckets) ||
+        (desc->n_materials && !desc->materials) || (desc->n_textures && !desc->textures) ||
+        (desc->n_transforms && !desc->transforms) || (desc->n_images && !desc->images) ||
+        (desc->n_perlins && !desc->perlins) || (desc->n_meshes && !desc->meshes) || (desc->n_groups && !desc->groups))
+        return rt_fail(RT_EINVAL, "scene description has a null table with a non-zero count");
+    Builder b(*desc, *out);
+    if (!b.run()) return rt_fail(b.status, "%s", b.err.c_str());
+    return RT_OK;
+}

@@ -1,0 +1,29 @@
+// rt_scene.h -- host-side staging of the device scene layout (see rt_device.h)
+#ifndef RT_SCENE_H
+#define RT_SCENE_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "rt_device.h"
+
+struct HostScene {
+    std::vector<float4> nodes; // 2 per node
+    std::vector<uint4> prims;  // 3 per primitive
+    std::vector<float> xforms; // 24 per transform
+    std::vector<uint4> materials;
+    std::vector<uint4> textures; // 2 per texture
+    std::vector<float> tri_attr; // 16 per triangle
+    std::vector<DevImage> images;
+    std::vector<uint8_t> image_data;
+    std::vector<float> perlin_vec;
+    std::vector<int32_t> perlin_perm;
+    std::vector<int32_t> prim_top, prim_sub;
+};
+
+// validates the description and fills `out`; returns an rtStatus and sets rt_last_error()
+int rt_flatten_scene(const rtSceneDesc* desc, HostScene* out);
+
+#endif

@@ -1,0 +1,140 @@
+"""Host-side mirror of the reference's public API for the accelerated path:
+render(...) (main.jl:21-96) with gpu=True, and the device half of draw! (src/Ray_Tracing.jl:141-157).
+The CPU branch of the reference (gpu=false) is the reference's own Julia code and is not
+reimplemented here: this package renders on the MI355X or not at all.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi as ffi
+from . import hittables as H
+from .scene_manager import SceneManager, build_bvh_scene, flatten_scene
+
+F = np.float32
+DEFAULT_SEED = 0x5EED
+
+
+def camera_record(cam):
+    c = ffi.rtCamera()
+    for name in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w"):
+        getattr(c, name)[:] = [float(x) for x in getattr(cam, name)]
+    c.lens_radius, c.t0, c.t1 = float(cam.lens_radius), float(cam.t0), float(cam.t1)
+    return c
+
+
+def _pattern(pattern):
+    """pattern is [x_0 ... x_n; y_0 ... y_n] (2 x N); the ABI wants it column-major like Julia stores it."""
+    p = np.asarray(pattern, dtype=F)
+    assert p.ndim == 2 and p.shape[0] == 2, "pattern must be 2 x N"
+    return np.ascontiguousarray(p.T).reshape(-1), p.shape[1]
+
+
+class DeviceScene:
+    """What draw!(::CuArray, ...) builds before its kernel launch (src/Ray_Tracing.jl:144-145):
+    bvh = build_bvh(world); cu_bvh = CuSceneManager(bvh) -- here a scene resident in one GPU's HBM."""
+
+    def __init__(self, world, device=0):
+        self.world = list(world)
+        self.scene_manager = SceneManager(self.world)
+        self.bvh = build_bvh_scene(self.scene_manager)
+        desc, keep = flatten_scene(self.world, self.bvh)
+        self._keep = keep
+        self.handle = C.c_void_p()
+        ffi.check(ffi.lib().rt_scene_create(C.byref(desc), int(device), C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            ffi.lib().rt_scene_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, camera, pattern, background, width, height, max_depth=50, seed=DEFAULT_SEED, flags=0):
+        """Returns (img, stats): img is (height, width, 3) float32, row 0 = top, sqrt-gamma, unclamped."""
+        pat, n = _pattern(pattern)
+        bg = np.asarray(background, dtype=F)
+        out = np.zeros(3 * width * height, dtype=F)
+        st = ffi.rtStats()
+        cam = camera_record(camera)
+        ffi.check(ffi.lib().rt_render(self.handle, C.byref(cam), ffi.fptr(pat), n, ffi.fptr(bg), width, height,
+                                      max_depth, seed, flags, ffi.fptr(out), C.byref(st)))
+        # Julia Array{RGB}(H, W) memory order is [col][row][rgb]
+        return out.reshape(width, height, 3).transpose(1, 0, 2).copy(), st
+
+    def accumulate(self, camera, pattern, background, width, height, d_accum, sample_first=0, sample_stride=1,
+                   max_depth=50, seed=DEFAULT_SEED, flags=0, stream=None):
+        """Un-normalised sums of this shard's samples into device memory (d_accum = device pointer)."""
+        pat, n = _pattern(pattern)
+        bg = np.asarray(background, dtype=F)
+        cam = camera_record(camera)
+        ffi.check(ffi.lib().rt_render_accumulate(self.handle, C.byref(cam), ffi.fptr(pat), n, sample_first,
+                                                 sample_stride, ffi.fptr(bg), width, height, max_depth, seed, flags,
+                                                 C.c_void_p(d_accum), C.c_void_p(stream or 0)))
+
+    def finalize(self, d_accum, n_total, width, height, d_out, stream=None):
+        ffi.check(ffi.lib().rt_finalize(self.handle, C.c_void_p(d_accum), n_total, width, height,
+                                        C.c_void_p(d_out), C.c_void_p(stream or 0)))
+
+    def counters(self):
+        st = ffi.rtStats()
+        ffi.check(ffi.lib().rt_get_counters(self.handle, C.byref(st)))
+        return st
+
+    def trace_rays(self, rays, t_min=0.001, t_max=np.inf, seed=DEFAULT_SEED):
+        rays = np.ascontiguousarray(rays, dtype=F).reshape(-1, 7)
+        n = rays.shape[0]
+        out = dict(prim_id=np.zeros(n, np.int32), sub_id=np.zeros(n, np.int32), t=np.zeros(n, F),
+                   normal=np.zeros((n, 3), F), uv=np.zeros((n, 2), F), front=np.zeros(n, np.uint8))
+        ffi.check(ffi.lib().rt_trace_rays(self.handle, ffi.fptr(rays), n, float(t_min), float(t_max), seed,
+                                          ffi.iptr(out["prim_id"]), ffi.iptr(out["sub_id"]), ffi.fptr(out["t"]),
+                                          ffi.fptr(out["normal"]), ffi.fptr(out["uv"]), ffi.bptr(out["front"])))
+        return out
+
+    def trace_paths(self, camera, pattern, background, width, height, ids, max_depth=50, seed=DEFAULT_SEED):
+        pat, n = _pattern(pattern)
+        bg = np.asarray(background, dtype=F)
+        ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(-1, 3)
+        rad = np.zeros((ids.shape[0], 3), dtype=F)
+        cam = camera_record(camera)
+        ffi.check(ffi.lib().rt_trace_paths(self.handle, C.byref(cam), ffi.fptr(pat), n, ffi.fptr(bg), width, height,
+                                           max_depth, seed, ffi.iptr(ids), ids.shape[0], ffi.fptr(rad)))
+        return rad
+
+
+def render(world, material=None, *, width=None, height=None, camera=None, background=None, pattern=None,
+           gpu=False, spp=None, seed=DEFAULT_SEED, device=0, **kwargs):
+    """render(world::Vector{<:Hittable}; ...), render(filename, material; ...) and render(key::Symbol; ...)
+    (main.jl:21-96).  Defaults as main.jl:22-27: 1280x720, Camera(), sky-blue background, MSAA_S16.
+    Returns an (height, width, 3) float32 image, row 0 = top, sqrt-gamma, unclamped."""
+    given = {k: v for k, v in dict(width=width, height=height, camera=camera, background=background,
+                                   pattern=pattern).items() if v is not None}
+    opts = dict(width=1280, height=720, camera=None, background=(0.70, 0.80, 1.00), pattern=None)
+    if isinstance(world, str) and material is not None:
+        # render(filename::String, material; kwargs...) (main.jl:53-81)
+        from .obj_loader import load_obj_mesh
+        world = [load_obj_mesh(world, material)]
+    elif isinstance(world, str):
+        # render(key::Symbol; gpu, kwargs...) (main.jl:90-94): scene values, overridden by the caller's kwargs
+        from .scenes import get_scene
+        world, scene_kwargs = get_scene(world, **({} if spp is None else {"spp": spp}))
+        opts.update(scene_kwargs)
+    opts.update(given)
+    if opts["camera"] is None:
+        opts["camera"] = H.Camera()
+    if opts["pattern"] is None:
+        opts["pattern"] = H.MSAA_S16.astype(F)
+    if not gpu:
+        raise NotImplementedError("gpu=False is the reference's own Julia CPU path; this package only provides "
+                                  "the MI355X path (gpu=True)")
+    scene = DeviceScene(world, device=device)
+    try:
+        img, _ = scene.render(opts["camera"], opts["pattern"], opts["background"], opts["width"], opts["height"],
+                              seed=seed)
+    finally:
+        scene.close()
+    return img
