@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpaths/s of the path-tracing loop on cu_cover2 (800x800, 1000 spp), the configuration
+BASELINE.json quotes, with the spp dimension sharded over N GPUs (one process per GPU) and the per-GPU
+accumulators summed by one RCCL all-reduce.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step is one whole frame: every rank traces its share of the pattern columns into an un-normalised FP32
+accumulator in HBM, the accumulators are all-reduced, and the image is finalised (x 1/N, sqrt) on the device.
+The scene, camera and pattern are resident on the GPU before the timed region starts.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Algorithmic cost per counted event of the reference algorithm (flops, bytes), from the formulas cited:
+#   node visit: src/bounding_box.jl:70-84 (6 sub, 6 mul, 3 min, 3 max, 3+3 for the 4-way max/min), 24 B box + 8 B links
+#   sphere: src/sphere.jl:46-63; rect: src/aarect.jl:50-57; box = 6 rects; transform: src/transform.jl:76-98,105-113
+#   triangle: src/triangle.jl:74-84; medium: two boundary tests + log; scatter per material: src/hittable.jl:36-75
+COST = {
+    "node": (24, 32), "sphere": (31, 16), "moving_sphere": (45, 36), "rect": (8, 20), "box": (48, 24),
+    "transform": (54, 96), "medium": (72, 40), "triangle": (52, 36),
+    "hit_completion": (25, 0), "raygen": (40, 8),
+    "lambertian": (29, 0), "metal": (42, 0), "dielectric": (45, 0), "isotropic": (17, 0), "emissive": (0, 0),
+}
+PEAK_FP32_TFLOPS = 157.3  # MI355X FP32 vector peak (spec), the compute roof of this kernel
+
+
+def algorithmic_work(st):
+    """(flops, bytes) per path from the event counts of the reference algorithm (counted by the CPU checker)."""
+    pt = list(st.prim_tests)
+    sc = list(st.scatters)
+    ev = {
+        "node": st.node_visits, "sphere": pt[1], "moving_sphere": pt[2], "rect": pt[3] + pt[4] + pt[5], "box": pt[6],
+        "transform": pt[7], "medium": pt[8], "triangle": pt[10], "hit_completion": sum(sc), "raygen": st.paths,
+        "lambertian": sc[1], "metal": sc[2], "dielectric": sc[3], "emissive": sc[4], "isotropic": sc[5],
+    }
+    flops = sum(ev[k] * COST[k][0] for k in ev)
+    nbytes = sum(ev[k] * COST[k][1] for k in ev)
+    return flops / st.paths, nbytes / st.paths, {k: v / st.paths for k, v in ev.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="cu_cover2")
+    ap.add_argument("--spp", type=int, default=1000)
+    ap.add_argument("--cpu-spp", type=int, default=6, help="pattern columns of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import raytracing_amd as rt
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    world, kw = rt.get_scene(args.scene, spp=args.spp)
+    W, H, cam, bg, pattern = kw["width"], kw["height"], kw["camera"], kw["background"], kw["pattern"]
+    n = pattern.shape[1]
+    scene = rt.DeviceScene(world, device=local_rank)
+    accum = torch.zeros(3 * W * H, dtype=torch.float32, device=dev)
+    out = torch.zeros(3 * W * H, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(k=None):
+        if k is not None:
+            ev0[k].record()
+        scene.accumulate(cam, pattern, bg, W, H, accum.data_ptr(), sample_first=rank, sample_stride=world_size,
+                         stream=stream)
+        if k is not None:
+            ev1[k].record()
+        if world_size > 1:
+            dist.all_reduce(accum)
+        scene.finalize(accum.data_ptr(), n, W, H, out.data_ptr(), stream=stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / max(1, args.steps)
+
+    if rank == 0:
+        paths_per_frame = W * H * n
+        value = paths_per_frame * args.steps / elapsed / 1e6
+        line = {
+            "metric": "Mpaths/s (whole node), %s %d spp" % (args.scene, n), "value": value, "unit": "Mpaths/s",
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / max(1, args.steps) * 1e3, "s_per_frame": elapsed / max(1, args.steps),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s %dx%d, %d spp (Halton), depth 50, seeded scene" % (args.scene, W, H, n),
+                       "parallelism": "spp sharded over %d GPU(s), RCCL all-reduce of the FP32 accumulator" % world_size,
+                       "paths_per_frame": paths_per_frame},
+        }
+        roofline, cpu = None, None
+        if not args.no_cpu and world_size == 1:
+            # bounded CPU sample: the checker (a C++ port of the reference's CPU path, threads over columns) renders
+            # the same scene at full resolution with a few pattern columns; it also counts the events of the
+            # reference algorithm, which define the algorithmic flops/bytes per path used for the roofline.
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_ffi as O
+            cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+            ref = O.OracleScene(world)
+            cpu_pat = rt.Halton_sequence32(args.cpu_spp)
+            _, st = ref.render(cam, cpu_pat, bg, W, H, threads=cores, stats=True)
+            cpu = {"value": st.paths / st.seconds / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
+                   "sample": "%s %dx%d, %d of %d pattern columns (%.1f s)" % (args.scene, W, H, args.cpu_spp, n, st.seconds)}
+            flops_pp, bytes_pp, events = algorithmic_work(st)
+            paths_per_launch = W * H * len(range(0, n, 1))
+            tflops = flops_pp * paths_per_launch / (kernel_ms * 1e-3) / 1e12
+            roofline = {"bound": "valu_fp32", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tflops / PEAK_FP32_TFLOPS, "traffic": None,
+                        "kernel": "rt_render_kernel", "kernel_ms": kernel_ms,
+                        "flops_per_path": flops_pp, "l2_bytes_per_path": bytes_pp,
+                        "node_fetch_GBps": bytes_pp * paths_per_launch / (kernel_ms * 1e-3) / 1e9,
+                        "events_per_path": {k: round(v, 3) for k, v in events.items()}}
+            pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(pmc):
+                with open(pmc) as f:
+                    roofline["traffic"] = json.load(f).get(args.scene)
+        line["roofline"] = roofline
+        line["cpu_baseline"] = cpu
+        print(json.dumps(line), flush=True)
+    scene.close()
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -157,6 +157,8 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     if (st != RT_OK) { rt_scene_destroy(s); return st; }
     s->dev.n_nodes = (uint32_t)(H.nodes.size() / 2);
     s->dev.n_prims = (uint32_t)(H.prims.size() / 3);
+    s->dev.surface_root = H.surface_root;
+    s->dev.medium_root = H.medium_root;
     *out = s;
     return RT_OK;
 }

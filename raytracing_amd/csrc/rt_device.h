@@ -7,7 +7,8 @@
 //             hit continues at node+1 (its first child) and every other case continues at `skip`
 //             (the next node in pre-order that is not a descendant).  leaf = primitive index + 1,
 //             0 for interior nodes.  The per-type trees of the host are laid out one after another,
-//             so one traversal covers the whole SceneManager.
+//             so one walk covers the whole SceneManager: first all trees of surfaces (ending in
+//             RT_NODE_END), then all trees of constant media (a second chain ending in RT_NODE_END).
 //   prims   : 48 B per primitive = 3 x uint4: {head, material, rank, g0}, {g1..g4}, {g5..g8}
 //             head = kind (bits 0-3) | medium flag (bit 4) | index field (bits 8-31):
 //             transform index + 1 (0 = none), or for triangles the attribute record index.
@@ -51,6 +52,8 @@ struct DevScene {
     const int32_t* prim_top;     // per primitive: position in the world vector (reported prim_id)
     const int32_t* prim_sub;     // per primitive: reported sub id base (triangle id / nested object index)
     uint32_t n_nodes, n_prims;
+    uint32_t surface_root; // first node of the surface trees, RT_NODE_END if there are none
+    uint32_t medium_root;  // first node of the constant-medium trees, RT_NODE_END if there are none
 };
 
 #endif

@@ -294,45 +294,88 @@ struct Counters {
 // (src/scene_manager.jl:40-53) over per-type trees traversed as in src/BVH.jl:22-53 / src/mesh.jl:115-163:
 // the closest hit wins; among exactly equal distances the reference keeps the earlier type group and, inside
 // a group, the leaf its right-child-first stack order reaches first -- encoded here as `rank`.
-template <bool COUNT>
-__device__ __forceinline__ void closest_hit(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max,
-                                            const RngKey& key, Closest& best, Counters& cnt) {
-    best.t = INF;
-    best.prim = 0xFFFFFFFFu;
-    best.sx = 0;
-    best.rank = 0;
-    if (COUNT) cnt.rays++;
+//
+// Two regions are walked one after the other: first every tree of surfaces, then the trees of constant media,
+// so that the (expensive, stochastic) medium test runs once per ray with the closest surface already known and
+// with the lanes of the wave converged.  Inside a region the walk is "while-while": an inner loop only steps
+// through nodes until the lane holds a leaf, then all lanes test their leaves together.
+struct RayFrame { // the ray in the frame being traversed, and one saved level for a nested tree
+    f3 o, d, inv;
+};
+
+__device__ __forceinline__ void consider(Closest& best, float& t_max, float t, uint32_t prim, uint32_t sx, uint32_t rank) {
+    if (t < best.t || (t == best.t && t != INF && rank > best.rank)) {
+        best.t = t;
+        best.prim = prim;
+        best.sx = sx;
+        best.rank = rank;
+        t_max = t;
+    }
+}
+
+// src/constant_medium.jl:29-65 for one medium primitive
+__device__ __forceinline__ float medium_t(const DevScene& S, uint32_t head, const float* g, f3 o, f3 d, float time,
+                                          float t_min, float t_max, const RngKey& key) {
+    uint32_t kind = head & 15u, field = head >> 8;
+    f3 ro = o, rd = d;
+    if (field) {
+        const float* T = S.xforms + 24u * (field - 1u) + 12;
+        ro = apply_point(T, o);
+        rd = apply_vec(T, d);
+    }
+    uint32_t s2;
+    float t1 = shape_t(kind, g, ro, rd, time, -INF, INF, s2);
+    if (t1 == INF) return INF;
+    float t2 = shape_t(kind, g, ro, rd, time, t1 + 0.0001f, INF, s2);
+    if (t2 == INF) return INF;
+    if (t1 < t_min) t1 = t_min;
+    if (t2 > t_max) t2 = t_max;
+    if (t1 >= t2) return INF;
+    if (t1 < 0.0f) t1 = 0.0f;
+    float ray_length = sqrtf(dot3(d, d));
+    float distance_inside = (t2 - t1) * ray_length;
+    u4 r = rng_draw(key, PURPOSE_MEDIUM, __float_as_uint(g[7]));
+    float hit_distance = g[6] * det_logf(u01(r.x));
+    if (hit_distance > distance_inside) return INF;
+    return t1 + hit_distance / ray_length;
+}
+
+template <bool COUNT, bool MEDIA>
+__device__ __forceinline__ void walk_region(const DevScene& S, uint32_t node, f3 o, f3 d, float time, float t_min,
+                                            float& t_max, const RngKey& key, Closest& best, Counters& cnt) {
     f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    // state for one level of nesting (a BVHTree used as an object inside a Transform)
+    // one level of nesting: a BVHTree used as an object inside a Transform
     f3 so = o, sd = d;
     uint32_t ret = RT_NODE_END, inst_rank = 0, inst_xf = 0;
-    uint32_t node = S.n_nodes ? 0u : RT_NODE_END;
     for (;;) {
-        if (node >= RT_NODE_END_SUB) {
+        uint32_t leaf = 0;
+        while (leaf == 0u && node < RT_NODE_END_SUB) {
+            float4 q0 = S.nodes[2u * node], q1 = S.nodes[2u * node + 1u];
+            if (COUNT) cnt.nodes++;
+            // Box test (src/bounding_box.jl:70-84 form).  It only culls: the far distance is widened by 8 ulp so
+            // that rounding can never reject a box that the exact slab test of src/bounding_box.jl:20-67 accepts;
+            // NaNs (0 * Inf) drop out of fminf/fmaxf, which keeps the axis unconstrained.
+            float tx0 = (q0.x - o.x) * inv.x, tx1 = (q1.x - o.x) * inv.x;
+            float ty0 = (q0.y - o.y) * inv.y, ty1 = (q1.y - o.y) * inv.y;
+            float tz0 = (q0.z - o.z) * inv.z, tz1 = (q1.z - o.z) * inv.z;
+            float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t_min));
+            float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), t_max));
+            tfar = __builtin_fmaf(fabsf(tfar), 4.8e-7f, tfar);
+            uint32_t skip = __float_as_uint(q0.w);
+            uint32_t lf = __float_as_uint(q1.w);
+            bool hit = tnear <= tfar;
+            node = (hit && lf == 0u) ? node + 1u : skip;
+            leaf = hit ? lf : 0u;
+        }
+        if (leaf == 0u) {
             if (node == RT_NODE_END) break;
+            // end of a nested tree: back to the outer ray
             o = so; d = sd;
             inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
             node = ret;
             inst_rank = 0; inst_xf = 0;
             continue;
         }
-        float4 q0 = S.nodes[2u * node], q1 = S.nodes[2u * node + 1u];
-        if (COUNT) cnt.nodes++;
-        // Box test (src/bounding_box.jl:70-84 form).  It only culls: the far distance is widened by 8 ulp so
-        // that rounding can never reject a box that the exact slab test of src/bounding_box.jl:20-67 accepts;
-        // NaNs (0 * Inf) drop out of fminf/fmaxf, which keeps the axis unconstrained.
-        float tx0 = (q0.x - o.x) * inv.x, tx1 = (q1.x - o.x) * inv.x;
-        float ty0 = (q0.y - o.y) * inv.y, ty1 = (q1.y - o.y) * inv.y;
-        float tz0 = (q0.z - o.z) * inv.z, tz1 = (q1.z - o.z) * inv.z;
-        float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t_min));
-        float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), t_max));
-        tfar = __builtin_fmaf(fabsf(tfar), 4.8e-7f, tfar);
-        uint32_t skip = __float_as_uint(q0.w);
-        uint32_t leaf = __float_as_uint(q1.w);
-        if (!(tnear <= tfar)) { node = skip; continue; }
-        if (leaf == 0u) { node = node + 1u; continue; }
-        node = skip;
-
         uint32_t prim = leaf - 1u;
         uint4 head;
         Geom G;
@@ -340,6 +383,12 @@ __device__ __forceinline__ void closest_hit(const DevScene& S, f3 o, f3 d, float
         if (COUNT) cnt.prims++;
         uint32_t kind = head.x & 15u;
         uint32_t field = head.x >> 8;
+        uint32_t rank = head.z + inst_rank;
+        if (MEDIA) {
+            float t = medium_t(S, head.x, G.g, o, d, time, t_min, t_max, key);
+            consider(best, t_max, t, prim, field << 3, rank);
+            continue;
+        }
         if (kind == DP_INSTANCE) {
             // Transform{BVHTree}: src/transform.jl:104-116 around src/BVH.jl:22-53
             so = o; sd = d;
@@ -369,39 +418,22 @@ __device__ __forceinline__ void closest_hit(const DevScene& S, f3 o, f3 d, float
                 rd = apply_vec(T, d);
                 xf = field;
             }
-            if (head.x & DP_MEDIUM_FLAG) {
-                // src/constant_medium.jl:29-65
-                uint32_t s2;
-                float t1 = shape_t(kind, G.g, ro, rd, time, -INF, INF, s2);
-                t = INF;
-                if (t1 != INF) {
-                    float t2 = shape_t(kind, G.g, ro, rd, time, t1 + 0.0001f, INF, s2);
-                    if (t2 != INF) {
-                        if (t1 < t_min) t1 = t_min;
-                        if (t2 > t_max) t2 = t_max;
-                        if (t1 < t2) {
-                            if (t1 < 0.0f) t1 = 0.0f;
-                            float ray_length = sqrtf(dot3(d, d));
-                            float distance_inside = (t2 - t1) * ray_length;
-                            u4 r = rng_draw(key, PURPOSE_MEDIUM, __float_as_uint(G.g[7]));
-                            float hit_distance = G.g[6] * det_logf(u01(r.x));
-                            if (!(hit_distance > distance_inside)) t = t1 + hit_distance / ray_length;
-                        }
-                    }
-                }
-            } else {
-                t = shape_t(kind, G.g, ro, rd, time, t_min, t_max, side);
-            }
+            t = shape_t(kind, G.g, ro, rd, time, t_min, t_max, side);
         }
-        uint32_t rank = head.z + inst_rank;
-        if (t < best.t || (t == best.t && t != INF && rank > best.rank)) {
-            best.t = t;
-            best.prim = prim;
-            best.sx = side | (xf << 3);
-            best.rank = rank;
-            t_max = t;
-        }
+        consider(best, t_max, t, prim, side | (xf << 3), rank);
     }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max,
+                                            const RngKey& key, Closest& best, Counters& cnt) {
+    best.t = INF;
+    best.prim = 0xFFFFFFFFu;
+    best.sx = 0;
+    best.rank = 0;
+    if (COUNT) cnt.rays++;
+    if (S.surface_root != RT_NODE_END) walk_region<COUNT, false>(S, S.surface_root, o, d, time, t_min, t_max, key, best, cnt);
+    if (S.medium_root != RT_NODE_END) walk_region<COUNT, true>(S, S.medium_root, o, d, time, t_min, t_max, key, best, cnt);
 }
 
 // ------------------------------------------------------------------ hit completion (only for the winner)
@@ -614,59 +646,64 @@ __device__ __forceinline__ float schlick(float cos_theta, float eta) {
     return r0 + (1.0f - r0) * x5;
 }
 
-// One path: trace(ray, scene; background, depth) of src/Ray_Tracing.jl:11-29 / :51-69
+// State of the path a lane is tracing: the loop variables of trace() (src/Ray_Tracing.jl:11-29 / :51-69)
+struct PathState {
+    f3 o, d;
+    float time;
+    f3 acc, color;
+    int depth;
+};
+
+// One iteration of the while loop of trace(): returns true when the path ended, with its radiance in `result`.
 template <bool COUNT>
-__device__ __forceinline__ f3 trace_path(const DevScene& S, f3 o, f3 d, float time, f3 background, int depth,
-                                         RngKey& key, Counters& cnt) {
-    f3 acc = mk3(1.0f, 1.0f, 1.0f);
-    f3 color = mk3(0.0f, 0.0f, 0.0f);
-    key.bounce = 0;
-    while (depth > 0) {
-        Closest best;
-        closest_hit<COUNT>(S, o, d, time, 0.001f, INF, key, best, cnt);
-        if (best.t == INF) return color + acc * background;
-        HitRec h;
-        complete_hit<false>(S, o, d, time, best, h);
-        uint4 m = S.materials[h.material];
-        uint32_t type = m.x & 0xFFu;
-        f3 att;
-        f3 emitted = mk3(0.0f, 0.0f, 0.0f);
-        f3 nd;
-        if (type == 1u) { // Lambertian
-            nd = h.n + normalize3(random_in_unit_sphere(key));
-            if (is_zero3(nd)) nd = h.n;
-            att = texture_value(S, m.y, h.u, h.v, h.p);
-        } else if (type == 2u) { // Metal
-            f3 reflected = reflect3(normalize3(d), h.n);
-            nd = reflected + __uint_as_float(m.z) * random_in_unit_sphere(key);
-            att = dot3(nd, h.n) > 0.0f ? texture_value(S, m.y, h.u, h.v, h.p) : mk3(0.0f, 0.0f, 0.0f);
-        } else if (type == 3u) { // Dielectric
-            float eta = __uint_as_float(m.w);
-            float ratio = h.front ? (1.0f / eta) : eta;
-            f3 unit_dir = normalize3(d);
-            float cos_theta = fminf(dot3(-unit_dir, h.n), 1.0f);
-            float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-            bool refl = ratio * sin_theta > 1.0f;
-            if (!refl) refl = schlick(cos_theta, eta) > u01(rng_draw(key, PURPOSE_SCALAR, 0).x);
-            nd = refl ? reflect3(unit_dir, h.n) : refract3(unit_dir, h.n, ratio);
-            att = mk3(1.0f, 1.0f, 1.0f);
-        } else if (type == 5u) { // Isotropic
-            nd = random_in_unit_sphere(key);
-            att = texture_value(S, m.y, h.u, h.v, h.p);
-        } else { // Emissive: zero ray, zero attenuation (src/hittable.jl:72-74), emits on both faces (:77-83)
-            nd = mk3(0.0f, 0.0f, 0.0f);
-            att = mk3(0.0f, 0.0f, 0.0f);
-            emitted = texture_value(S, m.y, h.u, h.v, h.p);
-        }
-        color = color + acc * emitted;
-        if (is_zero3(att)) return color;
-        acc = acc * att;
-        o = h.p;
-        d = nd;
-        depth -= 1;
-        key.bounce += 1;
+__device__ __forceinline__ bool trace_bounce(const DevScene& S, PathState& ps, f3 background, RngKey& key, Counters& cnt,
+                                             f3& result) {
+    if (ps.depth <= 0) { result = ps.color; return true; }
+    Closest best;
+    closest_hit<COUNT>(S, ps.o, ps.d, ps.time, 0.001f, INF, key, best, cnt);
+    if (best.t == INF) { result = ps.color + ps.acc * background; return true; }
+    HitRec h;
+    complete_hit<false>(S, ps.o, ps.d, ps.time, best, h);
+    uint4 m = S.materials[h.material];
+    uint32_t type = m.x & 0xFFu;
+    f3 att;
+    f3 emitted = mk3(0.0f, 0.0f, 0.0f);
+    f3 nd;
+    if (type == 1u) { // Lambertian
+        nd = h.n + normalize3(random_in_unit_sphere(key));
+        if (is_zero3(nd)) nd = h.n;
+        att = texture_value(S, m.y, h.u, h.v, h.p);
+    } else if (type == 2u) { // Metal
+        f3 reflected = reflect3(normalize3(ps.d), h.n);
+        nd = reflected + __uint_as_float(m.z) * random_in_unit_sphere(key);
+        att = dot3(nd, h.n) > 0.0f ? texture_value(S, m.y, h.u, h.v, h.p) : mk3(0.0f, 0.0f, 0.0f);
+    } else if (type == 3u) { // Dielectric
+        float eta = __uint_as_float(m.w);
+        float ratio = h.front ? (1.0f / eta) : eta;
+        f3 unit_dir = normalize3(ps.d);
+        float cos_theta = fminf(dot3(-unit_dir, h.n), 1.0f);
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        bool refl = ratio * sin_theta > 1.0f;
+        if (!refl) refl = schlick(cos_theta, eta) > u01(rng_draw(key, PURPOSE_SCALAR, 0).x);
+        nd = refl ? reflect3(unit_dir, h.n) : refract3(unit_dir, h.n, ratio);
+        att = mk3(1.0f, 1.0f, 1.0f);
+    } else if (type == 5u) { // Isotropic
+        nd = random_in_unit_sphere(key);
+        att = texture_value(S, m.y, h.u, h.v, h.p);
+    } else { // Emissive: zero ray, zero attenuation (src/hittable.jl:72-74), emits on both faces (:77-83)
+        nd = mk3(0.0f, 0.0f, 0.0f);
+        att = mk3(0.0f, 0.0f, 0.0f);
+        emitted = texture_value(S, m.y, h.u, h.v, h.p);
     }
-    return color;
+    ps.color = ps.color + ps.acc * emitted;
+    if (is_zero3(att)) { result = ps.color; return true; }
+    ps.acc = ps.acc * att;
+    ps.o = h.p;
+    ps.d = nd;
+    ps.depth -= 1;
+    key.bounce += 1;
+    if (ps.depth <= 0) { result = ps.color; return true; }
+    return false;
 }
 
 // get_ray (src/camera.jl:38-42) for pixel column i, row j (from the bottom), pattern column n
@@ -711,14 +748,31 @@ __global__ void __launch_bounds__(256) rt_render_kernel(DevScene S, RtCameraDev 
     key.seed32 = P.seed32;
     f3 bg = mk3(P.background[0], P.background[1], P.background[2]);
     f3 col = mk3(0.0f, 0.0f, 0.0f);
-    // shard sample k is pattern column sample_first + k*sample_stride; this chunk takes k = chunk, chunk + n_chunks, ...
-    for (uint32_t k = chunk; k < P.n_shard_samples; k += P.n_chunks) {
+    // Shard sample k is pattern column sample_first + k*sample_stride; this chunk takes k = chunk, chunk + n_chunks, ...
+    // The loop below runs one bounce per iteration; a lane whose path ends starts its next pattern column at
+    // once, so the lanes of a wave stay busy although their paths have different lengths.  Every lane still adds
+    // its paths in column order, exactly like the sample loop of draw! (src/Ray_Tracing.jl:82-89).
+    uint32_t k = chunk;
+    bool alive = k < P.n_shard_samples;
+    PathState ps;
+    auto start_path = [&]() {
         int n = P.sample_first + (int)k * P.sample_stride;
         key.sample = (uint32_t)n;
-        f3 o, d;
-        float time;
-        camera_ray(cam, pattern, i, j, n, P.width, P.height, key, o, d, time);
-        col = col + trace_path<COUNT>(S, o, d, time, bg, P.max_depth, key, cnt);
+        camera_ray(cam, pattern, i, j, n, P.width, P.height, key, ps.o, ps.d, ps.time);
+        ps.acc = mk3(1.0f, 1.0f, 1.0f);
+        ps.color = mk3(0.0f, 0.0f, 0.0f);
+        ps.depth = P.max_depth;
+        key.bounce = 0;
+    };
+    if (alive) start_path();
+    while (alive) {
+        f3 result;
+        if (trace_bounce<COUNT>(S, ps, bg, key, cnt, result)) {
+            col = col + result;
+            k += P.n_chunks;
+            alive = k < P.n_shard_samples;
+            if (alive) start_path();
+        }
     }
     size_t idx = ((size_t)i * (size_t)P.height + (size_t)(P.height - 1 - j)) * 3u; // img[height-j, i+1]
     float* dst = partial + (size_t)chunk * P.image_floats + idx;
@@ -792,7 +846,15 @@ __global__ void __launch_bounds__(256) rt_trace_paths_kernel(DevScene S, RtCamer
     f3 o, d;
     float time;
     camera_ray(cam, pattern, i, j, n, P.width, P.height, key, o, d, time);
-    f3 c = trace_path<false>(S, o, d, time, mk3(P.background[0], P.background[1], P.background[2]), P.max_depth, key, cnt);
+    PathState ps;
+    ps.o = o; ps.d = d; ps.time = time;
+    ps.acc = mk3(1.0f, 1.0f, 1.0f);
+    ps.color = mk3(0.0f, 0.0f, 0.0f);
+    ps.depth = P.max_depth;
+    key.bounce = 0;
+    f3 c = mk3(0.0f, 0.0f, 0.0f);
+    f3 bgc = mk3(P.background[0], P.background[1], P.background[2]);
+    while (!trace_bounce<false>(S, ps, bgc, key, cnt, c)) {}
     radiance[3 * k] = c.x; radiance[3 * k + 1] = c.y; radiance[3 * k + 2] = c.z;
 }
 

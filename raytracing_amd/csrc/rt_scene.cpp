@@ -327,17 +327,27 @@ struct Builder {
         }
         std::vector<uint32_t> base((size_t)D.n_buckets, 0);
         for (int b = D.n_buckets - 2; b >= 0; --b) base[(size_t)b] = base[(size_t)b + 1] + totals[(size_t)b + 1];
-        for (int b = 0; b < D.n_buckets; ++b) {
-            const rtBvh& T = D.buckets[b];
-            visited = 0;
-            bool ok = T.kind == 1 ? emit_mesh_level(T, 1, 0, base[(size_t)b], offsets[(size_t)b])
-                                  : emit_generic(T, 1, 0, H.nodes, base[(size_t)b], &offsets[(size_t)b], false, -1);
-            if (!ok) return false;
+        // region 0: trees of surfaces; region 1: trees of constant media (walked after all surfaces)
+        uint32_t region_start = 0;
+        for (int region = 0; region < 2; ++region) {
+            for (int b = 0; b < D.n_buckets; ++b) {
+                const rtBvh& T = D.buckets[b];
+                int first = T.objects[0];
+                bool is_medium = valid_obj(first) && D.objects[first].kind == RT_CONSTANT_MEDIUM;
+                if (is_medium != (region == 1)) continue;
+                visited = 0;
+                bool ok = T.kind == 1 ? emit_mesh_level(T, 1, 0, base[(size_t)b], offsets[(size_t)b])
+                                      : emit_generic(T, 1, 0, H.nodes, base[(size_t)b], &offsets[(size_t)b], false, -1);
+                if (!ok) return false;
+            }
+            uint32_t region_end = (uint32_t)(H.nodes.size() / 2);
+            for (uint32_t i = region_start; i < region_end; ++i)
+                if (fbits(H.nodes[2 * (size_t)i].w) == region_end) H.nodes[2 * (size_t)i].w = bitsf(RT_NODE_END);
+            if (region_end > region_start) (region == 0 ? H.surface_root : H.medium_root) = region_start;
+            region_start = region_end;
         }
-        // close the main region and append the nested trees behind it
+        // append the nested trees behind the two regions
         uint32_t main_count = (uint32_t)(H.nodes.size() / 2);
-        for (uint32_t i = 0; i < main_count; ++i)
-            if (fbits(H.nodes[2 * (size_t)i].w) == main_count) H.nodes[2 * (size_t)i].w = bitsf(RT_NODE_END);
         for (size_t i = 0; i < sub_nodes.size() / 2; ++i) {
             uint32_t s = fbits(sub_nodes[2 * i].w);
             if (s != RT_NODE_END_SUB) sub_nodes[2 * i].w = bitsf(s + main_count);

@@ -21,6 +21,7 @@ struct HostScene {
     std::vector<float> perlin_vec;
     std::vector<int32_t> perlin_perm;
     std::vector<int32_t> prim_top, prim_sub;
+    uint32_t surface_root = RT_NODE_END, medium_root = RT_NODE_END;
 };
 
 // validates the description and fills `out`; returns an rtStatus and sets rt_last_error()

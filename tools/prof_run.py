@@ -1,0 +1,14 @@
+"""One frame of a scene at a given spp, nothing else: the target command for rocprofv3 runs."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import raytracing_amd as rt
+name = sys.argv[1] if len(sys.argv) > 1 else "cu_cover2"
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+world, kw = rt.get_scene(name, spp=spp)
+dev = rt.DeviceScene(world)
+img, st = dev.render(kw["camera"], kw["pattern"], kw["background"], kw["width"], kw["height"], flags=flags)
+paths = kw["width"] * kw["height"] * spp
+print("%s %d spp: %.4f s, %.2f Mpaths/s" % (name, spp, st.seconds, paths / st.seconds / 1e6),
+      "rays/path %.3f nodes/ray %.2f prims/ray %.2f" % (st.rays / paths, st.node_visits / max(1, st.rays), st.prim_tests / max(1, st.rays)) if flags else "")
