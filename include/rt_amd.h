@@ -148,6 +148,9 @@ typedef struct rtStats {
     uint64_t rays;        /* hit(scene, ray) calls; 0 unless RT_FLAG_COUNTERS */
     uint64_t node_visits; /* BVH nodes fetched and slab-tested; 0 unless RT_FLAG_COUNTERS */
     uint64_t prim_tests;  /* leaf primitive tests; 0 unless RT_FLAG_COUNTERS */
+    /* wave-level loop iterations of the three loops (64 lanes each): lane utilisation of a loop =
+     * per-lane events / (64 * wave steps).  0 unless RT_FLAG_COUNTERS */
+    uint64_t node_wave_steps, prim_wave_steps, bounce_wave_steps;
 } rtStats;
 
 #define RT_FLAG_COUNTERS 1u /* run the counting variant of the kernel (slower) */

@@ -81,7 +81,8 @@ class rtCamera(C.Structure):
 
 class rtStats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("paths", C.c_uint64), ("rays", C.c_uint64),
-                ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64)]
+                ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64), ("node_wave_steps", C.c_uint64),
+                ("prim_wave_steps", C.c_uint64), ("bounce_wave_steps", C.c_uint64)]
 
 
 # every symbol include/rt_amd.h declares: name -> (restype, argtypes)

@@ -101,6 +101,10 @@ int fill_params(const float background[3], int width, int height, int max_depth,
     P->seed32 = fold_seed(seed);
     P->background[0] = background[0]; P->background[1] = background[1]; P->background[2] = background[2];
     P->image_floats = (size_t)3 * (size_t)width * (size_t)height;
+    const char* lt = std::getenv("RT_AMD_LEAF_THRESHOLD");
+    const char* sh = std::getenv("RT_AMD_SHADE_THRESHOLD");
+    P->leaf_threshold = lt && std::atoi(lt) > 0 ? (uint32_t)std::atoi(lt) : 16u;
+    P->shade_threshold = sh && std::atoi(sh) > 0 ? (uint32_t)std::atoi(sh) : 16u;
     return RT_OK;
 }
 
@@ -151,7 +155,7 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     if (st == RT_OK) st = upload(s, H.prim_top, &s->dev.prim_top);
     if (st == RT_OK) st = upload(s, H.prim_sub, &s->dev.prim_sub);
     if (st == RT_OK) {
-        hipError_t e2 = hipMalloc((void**)&s->d_counters, 4 * sizeof(unsigned long long));
+        hipError_t e2 = hipMalloc((void**)&s->d_counters, 8 * sizeof(unsigned long long));
         if (e2 != hipSuccess) st = rt_fail(RT_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e2));
     }
     if (st != RT_OK) { rt_scene_destroy(s); return st; }
@@ -197,7 +201,7 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
     if (st != RT_OK) return st;
     HIP_TRY(hipMemcpyAsync(s->d_pattern, pattern, (size_t)2 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, stream));
     bool count = (flags & RT_FLAG_COUNTERS) != 0;
-    if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), stream));
+    if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), stream));
     RtCameraDev cam;
     camera_to_dev(camera, &cam);
     rt_launch_render(&s->dev, &cam, s->d_pattern, &P, s->d_partial, s->d_counters, count, stream);
@@ -223,13 +227,16 @@ int rt_get_counters(rtScene* s, rtStats* stats) {
     if (!s || !stats) return rt_fail(RT_EINVAL, "rt_get_counters: null argument");
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->last_stream));
-    unsigned long long c[4] = {0, 0, 0, 0};
+    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     std::memset(stats, 0, sizeof(*stats));
     stats->paths = s->last_paths;
     stats->rays = c[0];
     stats->node_visits = c[1];
     stats->prim_tests = c[2];
+    stats->node_wave_steps = c[3];
+    stats->prim_wave_steps = c[4];
+    stats->bounce_wave_steps = c[5];
     return RT_OK;
 }
 

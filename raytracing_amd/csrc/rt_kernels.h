@@ -20,6 +20,7 @@ struct RtRenderParams {
     uint32_t tiles_x, tiles_y;       // 8x8-pixel tiles
     uint32_t seed32;
     float background[3];
+    uint32_t leaf_threshold, shade_threshold; // wave vote: run the leaf / shade block once this many lanes wait for it
     size_t image_floats;             // 3 * width * height
 };
 

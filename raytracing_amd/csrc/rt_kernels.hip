@@ -288,7 +288,12 @@ struct Closest {
 };
 struct Counters {
     uint32_t rays, nodes, prims;
+    uint32_t node_waves, prim_waves, bounce_waves; // wave-level iterations, counted by the first active lane
 };
+__device__ __forceinline__ uint32_t first_active_lane() {
+    unsigned long long m = __ballot(1);
+    return (uint32_t)(__ffsll((long long)m) - 1) == (threadIdx.x & 63u) ? 1u : 0u;
+}
 
 // Traversal of the flattened SceneManager.  Equivalent to hit(::SceneManager, ray, t_min, t_max)
 // (src/scene_manager.jl:40-53) over per-type trees traversed as in src/BVH.jl:22-53 / src/mesh.jl:115-163:
@@ -296,20 +301,47 @@ struct Counters {
 // a group, the leaf its right-child-first stack order reaches first -- encoded here as `rank`.
 //
 // Two regions are walked one after the other: first every tree of surfaces, then the trees of constant media,
-// so that the (expensive, stochastic) medium test runs once per ray with the closest surface already known and
-// with the lanes of the wave converged.  Inside a region the walk is "while-while": an inner loop only steps
-// through nodes until the lane holds a leaf, then all lanes test their leaves together.
-struct RayFrame { // the ray in the frame being traversed, and one saved level for a nested tree
-    f3 o, d, inv;
+// so that the (expensive, stochastic) medium test runs once per ray with the closest surface already known.
+//
+// The walk is written as a per-lane state machine with two blocks, walker_step (fetch one node, box test) and
+// walker_leaf (test the pending leaf primitive).  The kernels run these blocks under a wave-wide vote (see
+// rt_render_kernel): at every iteration the 64 lanes of the wave execute the one block that most lanes are
+// waiting for, instead of each lane dragging the whole wave through its own control flow.
+struct Walker {
+    f3 o, d, inv;              // ray in the frame being traversed (inv = 1/d for the box test)
+    float time, t_min, t_max;  // t_max shrinks to the closest hit found so far
+    f3 so, sd;                 // outer ray while inside a nested tree (a BVHTree inside a Transform)
+    uint32_t ret, inst_rank, inst_xf;
+    uint32_t node;             // next node to visit, RT_NODE_END / RT_NODE_END_SUB at the end of a region
+    uint32_t leaf;             // pending leaf: primitive index + 1, 0 = none
+    uint32_t in_media;         // 1 while walking the constant-medium trees
+    Closest best;
 };
 
-__device__ __forceinline__ void consider(Closest& best, float& t_max, float t, uint32_t prim, uint32_t sx, uint32_t rank) {
-    if (t < best.t || (t == best.t && t != INF && rank > best.rank)) {
-        best.t = t;
-        best.prim = prim;
-        best.sx = sx;
-        best.rank = rank;
-        t_max = t;
+__device__ __forceinline__ void walker_start(Walker& W, const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max) {
+    W.o = o; W.d = d;
+    W.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    W.time = time; W.t_min = t_min; W.t_max = t_max;
+    W.so = o; W.sd = d;
+    W.ret = RT_NODE_END; W.inst_rank = 0; W.inst_xf = 0;
+    W.node = S.surface_root;
+    W.leaf = 0;
+    W.in_media = 0;
+    W.best.t = INF; W.best.prim = 0xFFFFFFFFu; W.best.sx = 0; W.best.rank = 0;
+}
+__device__ __forceinline__ bool walker_finished(const Walker& W) {
+    return W.leaf == 0u && W.node == RT_NODE_END && W.in_media != 0u;
+}
+__device__ __forceinline__ bool walker_wants_leaf(const Walker& W) { return W.leaf != 0u; }
+__device__ __forceinline__ bool walker_wants_step(const Walker& W) { return W.leaf == 0u && !walker_finished(W); }
+
+__device__ __forceinline__ void consider(Walker& W, float t, uint32_t prim, uint32_t sx, uint32_t rank) {
+    if (t < W.best.t || (t == W.best.t && t != INF && rank > W.best.rank)) {
+        W.best.t = t;
+        W.best.prim = prim;
+        W.best.sx = sx;
+        W.best.rank = rank;
+        W.t_max = t;
     }
 }
 
@@ -340,100 +372,120 @@ __device__ __forceinline__ float medium_t(const DevScene& S, uint32_t head, cons
     return t1 + hit_distance / ray_length;
 }
 
-template <bool COUNT, bool MEDIA>
-__device__ __forceinline__ void walk_region(const DevScene& S, uint32_t node, f3 o, f3 d, float time, float t_min,
-                                            float& t_max, const RngKey& key, Closest& best, Counters& cnt) {
-    f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    // one level of nesting: a BVHTree used as an object inside a Transform
-    f3 so = o, sd = d;
-    uint32_t ret = RT_NODE_END, inst_rank = 0, inst_xf = 0;
-    for (;;) {
-        uint32_t leaf = 0;
-        while (leaf == 0u && node < RT_NODE_END_SUB) {
-            float4 q0 = S.nodes[2u * node], q1 = S.nodes[2u * node + 1u];
-            if (COUNT) cnt.nodes++;
-            // Box test (src/bounding_box.jl:70-84 form).  It only culls: the far distance is widened by 8 ulp so
-            // that rounding can never reject a box that the exact slab test of src/bounding_box.jl:20-67 accepts;
-            // NaNs (0 * Inf) drop out of fminf/fmaxf, which keeps the axis unconstrained.
-            float tx0 = (q0.x - o.x) * inv.x, tx1 = (q1.x - o.x) * inv.x;
-            float ty0 = (q0.y - o.y) * inv.y, ty1 = (q1.y - o.y) * inv.y;
-            float tz0 = (q0.z - o.z) * inv.z, tz1 = (q1.z - o.z) * inv.z;
-            float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t_min));
-            float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), t_max));
-            tfar = __builtin_fmaf(fabsf(tfar), 4.8e-7f, tfar);
-            uint32_t skip = __float_as_uint(q0.w);
-            uint32_t lf = __float_as_uint(q1.w);
-            bool hit = tnear <= tfar;
-            node = (hit && lf == 0u) ? node + 1u : skip;
-            leaf = hit ? lf : 0u;
-        }
-        if (leaf == 0u) {
-            if (node == RT_NODE_END) break;
-            // end of a nested tree: back to the outer ray
-            o = so; d = sd;
-            inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-            node = ret;
-            inst_rank = 0; inst_xf = 0;
-            continue;
-        }
-        uint32_t prim = leaf - 1u;
-        uint4 head;
-        Geom G;
-        load_prim(S, prim, head, G);
-        if (COUNT) cnt.prims++;
-        uint32_t kind = head.x & 15u;
-        uint32_t field = head.x >> 8;
-        uint32_t rank = head.z + inst_rank;
-        if (MEDIA) {
-            float t = medium_t(S, head.x, G.g, o, d, time, t_min, t_max, key);
-            consider(best, t_max, t, prim, field << 3, rank);
-            continue;
-        }
-        if (kind == DP_INSTANCE) {
-            // Transform{BVHTree}: src/transform.jl:104-116 around src/BVH.jl:22-53
-            so = o; sd = d;
-            ret = node;
-            inst_rank = head.z;
-            inst_xf = field;
-            if (field) {
-                const float* T = S.xforms + 24u * (field - 1u) + 12;
-                f3 no = apply_point(T, o), nd = apply_vec(T, d);
-                o = no; d = nd;
-                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-            }
-            node = __float_as_uint(G.g[0]);
-            continue;
-        }
-        float t;
-        uint32_t side = 0, xf = inst_xf;
-        if (kind == DP_TRIANGLE) {
-            f3 nrm;
-            float u, v;
-            t = triangle_t(G.g, o, d, t_min, t_max, nrm, u, v);
-        } else {
-            f3 ro = o, rd = d;
-            if (field) { // Transform: src/transform.jl:104-105
-                const float* T = S.xforms + 24u * (field - 1u) + 12;
-                ro = apply_point(T, o);
-                rd = apply_vec(T, d);
-                xf = field;
-            }
-            t = shape_t(kind, G.g, ro, rd, time, t_min, t_max, side);
-        }
-        consider(best, t_max, t, prim, side | (xf << 3), rank);
+// One node: region bookkeeping, then fetch + box test.  Call only for lanes with walker_wants_step().
+template <bool COUNT>
+__device__ __forceinline__ void walker_step(Walker& W, const DevScene& S, Counters& cnt) {
+    if (W.node == RT_NODE_END_SUB) { // end of a nested tree: back to the outer ray
+        W.o = W.so; W.d = W.sd;
+        W.inv = mk3(1.0f / W.d.x, 1.0f / W.d.y, 1.0f / W.d.z);
+        W.node = W.ret;
+        W.inst_rank = 0; W.inst_xf = 0;
+    }
+    if (W.node == RT_NODE_END && W.in_media == 0u) { // surfaces done: continue with the media
+        W.node = S.medium_root;
+        W.in_media = 1u;
+    }
+    if (W.node < RT_NODE_END_SUB) {
+        float4 q0 = S.nodes[2u * W.node], q1 = S.nodes[2u * W.node + 1u];
+        if (COUNT) cnt.nodes++;
+        // Box test (src/bounding_box.jl:70-84 form).  It only culls: the far distance is widened by 8 ulp so
+        // that rounding can never reject a box that the exact slab test of src/bounding_box.jl:20-67 accepts;
+        // NaNs (0 * Inf) drop out of fminf/fmaxf, which keeps the axis unconstrained.
+        float tx0 = (q0.x - W.o.x) * W.inv.x, tx1 = (q1.x - W.o.x) * W.inv.x;
+        float ty0 = (q0.y - W.o.y) * W.inv.y, ty1 = (q1.y - W.o.y) * W.inv.y;
+        float tz0 = (q0.z - W.o.z) * W.inv.z, tz1 = (q1.z - W.o.z) * W.inv.z;
+        float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), W.t_min));
+        float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), W.t_max));
+        tfar = __builtin_fmaf(fabsf(tfar), 4.8e-7f, tfar);
+        uint32_t skip = __float_as_uint(q0.w);
+        uint32_t lf = __float_as_uint(q1.w);
+        bool hit = tnear <= tfar;
+        W.node = (hit && lf == 0u) ? W.node + 1u : skip;
+        W.leaf = hit ? lf : 0u;
     }
 }
 
+// The pending leaf primitive.  Call only for lanes with walker_wants_leaf().
+template <bool COUNT>
+__device__ __forceinline__ void walker_leaf(Walker& W, const DevScene& S, const RngKey& key, Counters& cnt) {
+    uint32_t prim = W.leaf - 1u;
+    W.leaf = 0u;
+    uint4 head;
+    Geom G;
+    load_prim(S, prim, head, G);
+    if (COUNT) cnt.prims++;
+    uint32_t kind = head.x & 15u;
+    uint32_t field = head.x >> 8;
+    uint32_t rank = head.z + W.inst_rank;
+    if (W.in_media) {
+        float t = medium_t(S, head.x, G.g, W.o, W.d, W.time, W.t_min, W.t_max, key);
+        consider(W, t, prim, field << 3, rank);
+        return;
+    }
+    if (kind == DP_INSTANCE) {
+        // Transform{BVHTree}: src/transform.jl:104-116 around src/BVH.jl:22-53
+        W.so = W.o; W.sd = W.d;
+        W.ret = W.node;
+        W.inst_rank = head.z;
+        W.inst_xf = field;
+        if (field) {
+            const float* T = S.xforms + 24u * (field - 1u) + 12;
+            f3 no = apply_point(T, W.o), nd = apply_vec(T, W.d);
+            W.o = no; W.d = nd;
+            W.inv = mk3(1.0f / nd.x, 1.0f / nd.y, 1.0f / nd.z);
+        }
+        W.node = __float_as_uint(G.g[0]);
+        return;
+    }
+    float t;
+    uint32_t side = 0, xf = W.inst_xf;
+    if (kind == DP_TRIANGLE) {
+        f3 nrm;
+        float u, v;
+        t = triangle_t(G.g, W.o, W.d, W.t_min, W.t_max, nrm, u, v);
+    } else {
+        f3 ro = W.o, rd = W.d;
+        if (field) { // Transform: src/transform.jl:104-105
+            const float* T = S.xforms + 24u * (field - 1u) + 12;
+            ro = apply_point(T, W.o);
+            rd = apply_vec(T, W.d);
+            xf = field;
+        }
+        t = shape_t(kind, G.g, ro, rd, W.time, W.t_min, W.t_max, side);
+    }
+    consider(W, t, prim, side | (xf << 3), rank);
+}
+
+// Wave-wide vote: which block should the wave run now?  0 = step, 1 = leaf, 2 = shade, 3 = nothing left.
+// A block runs when enough lanes wait for it (thresholds) or when nothing cheaper is pending.
+struct Vote {
+    uint32_t leaf_threshold, shade_threshold;
+};
+__device__ __forceinline__ int wave_vote(bool ws, bool wl, bool wh, const Vote& V) {
+    uint32_t ns = (uint32_t)__popcll(__ballot(ws));
+    uint32_t nl = (uint32_t)__popcll(__ballot(wl));
+    uint32_t nh = (uint32_t)__popcll(__ballot(wh));
+    if ((ns | nl | nh) == 0u) return 3;
+    if (nh >= V.shade_threshold || (ns == 0u && nl == 0u)) return 2;
+    if (nl >= V.leaf_threshold || ns == 0u) return 1;
+    return 0;
+}
+
+// closest hit of one ray per lane (used by the ray parity hook)
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max,
-                                            const RngKey& key, Closest& best, Counters& cnt) {
-    best.t = INF;
-    best.prim = 0xFFFFFFFFu;
-    best.sx = 0;
-    best.rank = 0;
-    if (COUNT) cnt.rays++;
-    if (S.surface_root != RT_NODE_END) walk_region<COUNT, false>(S, S.surface_root, o, d, time, t_min, t_max, key, best, cnt);
-    if (S.medium_root != RT_NODE_END) walk_region<COUNT, true>(S, S.medium_root, o, d, time, t_min, t_max, key, best, cnt);
+                                            const RngKey& key, Closest& best, Counters& cnt, bool active) {
+    Walker W;
+    walker_start(W, S, o, d, time, t_min, t_max);
+    Vote V = {16u, 64u};
+    for (;;) {
+        bool ws = active && walker_wants_step(W), wl = active && walker_wants_leaf(W);
+        int block = wave_vote(ws, wl, false, V);
+        if (block == 3) break;
+        if (block == 0) { if (ws) walker_step<COUNT>(W, S, cnt); }
+        else { if (wl) walker_leaf<COUNT>(W, S, key, cnt); }
+    }
+    best = W.best;
 }
 
 // ------------------------------------------------------------------ hit completion (only for the winner)
@@ -648,22 +700,18 @@ __device__ __forceinline__ float schlick(float cos_theta, float eta) {
 
 // State of the path a lane is tracing: the loop variables of trace() (src/Ray_Tracing.jl:11-29 / :51-69)
 struct PathState {
-    f3 o, d;
-    float time;
     f3 acc, color;
     int depth;
 };
 
-// One iteration of the while loop of trace(): returns true when the path ended, with its radiance in `result`.
-template <bool COUNT>
-__device__ __forceinline__ bool trace_bounce(const DevScene& S, PathState& ps, f3 background, RngKey& key, Counters& cnt,
-                                             f3& result) {
-    if (ps.depth <= 0) { result = ps.color; return true; }
-    Closest best;
-    closest_hit<COUNT>(S, ps.o, ps.d, ps.time, 0.001f, INF, key, best, cnt);
-    if (best.t == INF) { result = ps.color + ps.acc * background; return true; }
+// The body of the while loop of trace() after hit(scene, ray) returned (the finished walker W holds the ray and
+// its closest hit).  Returns true when the path ended, with its radiance in `result`; otherwise W is restarted
+// on the scattered ray.
+__device__ __forceinline__ bool shade(const DevScene& S, Walker& W, PathState& ps, f3 background, RngKey& key, f3& result) {
+    if (W.best.t == INF) { result = ps.color + ps.acc * background; return true; }
+    f3 o = W.inst_xf ? W.so : W.o, d = W.inst_xf ? W.sd : W.d; // (a finished walker is always back in the outer frame)
     HitRec h;
-    complete_hit<false>(S, ps.o, ps.d, ps.time, best, h);
+    complete_hit<false>(S, o, d, W.time, W.best, h);
     uint4 m = S.materials[h.material];
     uint32_t type = m.x & 0xFFu;
     f3 att;
@@ -674,13 +722,13 @@ __device__ __forceinline__ bool trace_bounce(const DevScene& S, PathState& ps, f
         if (is_zero3(nd)) nd = h.n;
         att = texture_value(S, m.y, h.u, h.v, h.p);
     } else if (type == 2u) { // Metal
-        f3 reflected = reflect3(normalize3(ps.d), h.n);
+        f3 reflected = reflect3(normalize3(d), h.n);
         nd = reflected + __uint_as_float(m.z) * random_in_unit_sphere(key);
         att = dot3(nd, h.n) > 0.0f ? texture_value(S, m.y, h.u, h.v, h.p) : mk3(0.0f, 0.0f, 0.0f);
     } else if (type == 3u) { // Dielectric
         float eta = __uint_as_float(m.w);
         float ratio = h.front ? (1.0f / eta) : eta;
-        f3 unit_dir = normalize3(ps.d);
+        f3 unit_dir = normalize3(d);
         float cos_theta = fminf(dot3(-unit_dir, h.n), 1.0f);
         float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
         bool refl = ratio * sin_theta > 1.0f;
@@ -698,11 +746,10 @@ __device__ __forceinline__ bool trace_bounce(const DevScene& S, PathState& ps, f
     ps.color = ps.color + ps.acc * emitted;
     if (is_zero3(att)) { result = ps.color; return true; }
     ps.acc = ps.acc * att;
-    ps.o = h.p;
-    ps.d = nd;
     ps.depth -= 1;
     key.bounce += 1;
     if (ps.depth <= 0) { result = ps.color; return true; }
+    walker_start(W, S, h.p, nd, W.time, 0.001f, INF);
     return false;
 }
 
@@ -742,36 +789,58 @@ __global__ void __launch_bounds__(256) rt_render_kernel(DevScene S, RtCameraDev 
     int i = (int)((tile % P.tiles_x) * 8u + (lane & 7u));
     int j = (int)((tile / P.tiles_x) * 8u + (lane >> 3));
     if (i >= P.width || j >= P.height) return;
-    Counters cnt = {0, 0, 0};
+    Counters cnt = {0, 0, 0, 0, 0, 0};
     RngKey key;
     key.pixel = (uint32_t)j * (uint32_t)P.width + (uint32_t)i;
     key.seed32 = P.seed32;
     f3 bg = mk3(P.background[0], P.background[1], P.background[2]);
     f3 col = mk3(0.0f, 0.0f, 0.0f);
     // Shard sample k is pattern column sample_first + k*sample_stride; this chunk takes k = chunk, chunk + n_chunks, ...
-    // The loop below runs one bounce per iteration; a lane whose path ends starts its next pattern column at
-    // once, so the lanes of a wave stay busy although their paths have different lengths.  Every lane still adds
-    // its paths in column order, exactly like the sample loop of draw! (src/Ray_Tracing.jl:82-89).
+    // Every lane adds its paths in column order, exactly like the sample loop of draw! (src/Ray_Tracing.jl:82-89).
+    //
+    // The wave runs a voted state machine: each lane is either stepping through BVH nodes, holding a leaf to
+    // test, or holding a finished ray to shade (after which it continues its path or starts its next column at
+    // once).  Per iteration the wave executes the block chosen by wave_vote() for the lanes waiting for it.
     uint32_t k = chunk;
     bool alive = k < P.n_shard_samples;
     PathState ps;
+    Walker W;
+    Vote V = {P.leaf_threshold, P.shade_threshold};
     auto start_path = [&]() {
         int n = P.sample_first + (int)k * P.sample_stride;
         key.sample = (uint32_t)n;
-        camera_ray(cam, pattern, i, j, n, P.width, P.height, key, ps.o, ps.d, ps.time);
+        f3 o, d;
+        float time;
+        camera_ray(cam, pattern, i, j, n, P.width, P.height, key, o, d, time);
         ps.acc = mk3(1.0f, 1.0f, 1.0f);
         ps.color = mk3(0.0f, 0.0f, 0.0f);
         ps.depth = P.max_depth;
         key.bounce = 0;
+        walker_start(W, S, o, d, time, 0.001f, INF);
+        if (COUNT) cnt.rays++;
     };
+    walker_start(W, S, mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 1.0f), 0.0f, 0.001f, INF);
     if (alive) start_path();
-    while (alive) {
-        f3 result;
-        if (trace_bounce<COUNT>(S, ps, bg, key, cnt, result)) {
-            col = col + result;
-            k += P.n_chunks;
-            alive = k < P.n_shard_samples;
-            if (alive) start_path();
+    for (;;) {
+        bool ws = alive && walker_wants_step(W), wl = alive && walker_wants_leaf(W), wh = alive && walker_finished(W);
+        int block = wave_vote(ws, wl, wh, V);
+        if (block == 3) break;
+        if (block == 0) {
+            if (ws) { if (COUNT) cnt.node_waves += first_active_lane(); walker_step<COUNT>(W, S, cnt); }
+        } else if (block == 1) {
+            if (wl) { if (COUNT) cnt.prim_waves += first_active_lane(); walker_leaf<COUNT>(W, S, key, cnt); }
+        } else if (wh) {
+            if (COUNT) cnt.bounce_waves += first_active_lane();
+            f3 result;
+            bool done = ps.depth <= 0;
+            if (done) result = ps.color;
+            else done = shade(S, W, ps, bg, key, result);
+            if (done) {
+                col = col + result;
+                k += P.n_chunks;
+                alive = k < P.n_shard_samples;
+                if (alive) start_path();
+            } else if (COUNT) cnt.rays++;
         }
     }
     size_t idx = ((size_t)i * (size_t)P.height + (size_t)(P.height - 1 - j)) * 3u; // img[height-j, i+1]
@@ -781,6 +850,9 @@ __global__ void __launch_bounds__(256) rt_render_kernel(DevScene S, RtCameraDev 
         atomicAdd(&counters[0], (unsigned long long)cnt.rays);
         atomicAdd(&counters[1], (unsigned long long)cnt.nodes);
         atomicAdd(&counters[2], (unsigned long long)cnt.prims);
+        atomicAdd(&counters[3], (unsigned long long)cnt.node_waves);
+        atomicAdd(&counters[4], (unsigned long long)cnt.prim_waves);
+        atomicAdd(&counters[5], (unsigned long long)cnt.bounce_waves);
     }
 }
 
@@ -807,14 +879,16 @@ __global__ void __launch_bounds__(256) rt_trace_rays_kernel(DevScene S, const fl
                                                             int32_t* sub_id, float* t_out, float* normal, float* uv,
                                                             uint8_t* front) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
+    bool active = k < n;
+    if (!active) k = 0;
     const float* q = rays + 7 * (size_t)k;
     f3 o = mk3(q[0], q[1], q[2]), d = mk3(q[3], q[4], q[5]);
     float time = q[6];
     RngKey key = {(uint32_t)k, 0u, seed32, 0u};
-    Counters cnt = {0, 0, 0};
+    Counters cnt = {0, 0, 0, 0, 0, 0};
     Closest best;
-    closest_hit<false>(S, o, d, time, t_min, t_max, key, best, cnt);
+    closest_hit<false>(S, o, d, time, t_min, t_max, key, best, cnt, active);
+    if (!active) return;
     HitRec h;
     h.p = mk3(INF, INF, INF); h.n = mk3(0, 0, 0); h.u = 0; h.v = 0; h.front = false; h.material = 0;
     int pid = -1, sid = -1;
@@ -836,25 +910,41 @@ __global__ void __launch_bounds__(256) rt_trace_paths_kernel(DevScene S, RtCamer
                                                              RtRenderParams P, const int32_t* __restrict__ ids,
                                                              int n_paths, float* __restrict__ radiance) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_paths) return;
+    bool alive = k < n_paths;
+    if (!alive) k = 0;
     int i = ids[3 * k], j = ids[3 * k + 1], n = ids[3 * k + 2];
     RngKey key;
     key.pixel = (uint32_t)j * (uint32_t)P.width + (uint32_t)i;
     key.sample = (uint32_t)n;
     key.seed32 = P.seed32;
-    Counters cnt = {0, 0, 0};
+    Counters cnt = {0, 0, 0, 0, 0, 0};
     f3 o, d;
     float time;
     camera_ray(cam, pattern, i, j, n, P.width, P.height, key, o, d, time);
     PathState ps;
-    ps.o = o; ps.d = d; ps.time = time;
     ps.acc = mk3(1.0f, 1.0f, 1.0f);
     ps.color = mk3(0.0f, 0.0f, 0.0f);
     ps.depth = P.max_depth;
     key.bounce = 0;
     f3 c = mk3(0.0f, 0.0f, 0.0f);
     f3 bgc = mk3(P.background[0], P.background[1], P.background[2]);
-    while (!trace_bounce<false>(S, ps, bgc, key, cnt, c)) {}
+    Walker W;
+    walker_start(W, S, o, d, time, 0.001f, INF);
+    Vote V = {P.leaf_threshold, P.shade_threshold};
+    for (;;) {
+        bool ws = alive && walker_wants_step(W), wl = alive && walker_wants_leaf(W), wh = alive && walker_finished(W);
+        int block = wave_vote(ws, wl, wh, V);
+        if (block == 3) break;
+        if (block == 0) { if (ws) walker_step<false>(W, S, cnt); }
+        else if (block == 1) { if (wl) walker_leaf<false>(W, S, key, cnt); }
+        else if (wh) {
+            bool done = ps.depth <= 0;
+            if (done) c = ps.color;
+            else done = shade(S, W, ps, bgc, key, c);
+            if (done) alive = false;
+        }
+    }
+    if (k >= n_paths || blockIdx.x * blockDim.x + threadIdx.x >= (unsigned)n_paths) return;
     radiance[3 * k] = c.x; radiance[3 * k + 1] = c.y; radiance[3 * k + 2] = c.z;
 }
 
