@@ -40,14 +40,26 @@ struct rtScene {
     int n_buffers = 0;
     // scratch owned by the handle, grown on demand
     float* d_pattern = nullptr; size_t pattern_cap = 0;
-    float* d_partial = nullptr; size_t partial_cap = 0;
+    float4* d_radiance = nullptr; size_t radiance_cap = 0; // one entry per path of the batch in flight
+    float4* d_pool = nullptr;   size_t pool_cap = 0;   // path state planes of the wavefront renderer
+    uint32_t* d_sync = nullptr;                        // [0] slot dispenser head, [1..] active-slot counts per bounce
+    uint32_t* h_sync = nullptr;                        // pinned mirror of the active counts
+    int n_cus = 0;
     float* d_accum = nullptr;   size_t accum_cap = 0;
     unsigned long long* d_counters = nullptr;
     hipStream_t last_stream = nullptr;
     uint64_t last_paths = 0;
 };
 
+#define SYNC_WORDS 4096u   // word 0: slot dispenser; words 1..: ring of per-bounce active counts
+#define BOUNCE_BATCH 16u   // bounces enqueued between two looks at the active count
+
 namespace {
+
+int env_int(const char* name, int fallback) {
+    const char* v = std::getenv(name);
+    return v && std::atoi(v) > 0 ? std::atoi(v) : fallback;
+}
 
 template <typename T>
 int upload(rtScene* s, const std::vector<T>& v, const T** out) {
@@ -77,19 +89,6 @@ void camera_to_dev(const rtCamera* c, RtCameraDev* d) {
     std::memcpy(d, c, sizeof(*d));
 }
 
-uint32_t pick_chunks(uint32_t n_tiles, uint32_t n_samples) {
-    // enough waves to keep 256 CUs busy for several rounds, but at least 4 pattern columns per lane
-    const char* env = std::getenv("RT_AMD_CHUNKS");
-    uint32_t chunks;
-    if (env && std::atoi(env) > 0) chunks = (uint32_t)std::atoi(env);
-    else chunks = (32768u + n_tiles - 1u) / n_tiles;
-    uint32_t cap = n_samples / 4u;
-    if (cap < 1u) cap = 1u;
-    if (chunks > cap) chunks = cap;
-    if (chunks < 1u) chunks = 1u;
-    return chunks;
-}
-
 int fill_params(const float background[3], int width, int height, int max_depth, uint64_t seed, RtRenderParams* P) {
     if (width < 2 || height < 2) return rt_fail(RT_EINVAL, "width and height must be at least 2 (the reference divides by width-1 and height-1)");
     if ((uint64_t)width * (uint64_t)height > 0x7FFFFFFFull / 3ull) return rt_fail(RT_EINVAL, "image too large");
@@ -97,14 +96,13 @@ int fill_params(const float background[3], int width, int height, int max_depth,
     if (!background) return rt_fail(RT_EINVAL, "background is null");
     std::memset(P, 0, sizeof(*P));
     P->width = width; P->height = height; P->max_depth = max_depth;
-    P->tiles_x = (uint32_t)(width + 7) / 8u; P->tiles_y = (uint32_t)(height + 7) / 8u;
+    P->n_pixels = (uint32_t)width * (uint32_t)height;
     P->seed32 = fold_seed(seed);
     P->background[0] = background[0]; P->background[1] = background[1]; P->background[2] = background[2];
     P->image_floats = (size_t)3 * (size_t)width * (size_t)height;
-    const char* lt = std::getenv("RT_AMD_LEAF_THRESHOLD");
-    const char* sh = std::getenv("RT_AMD_SHADE_THRESHOLD");
-    P->leaf_threshold = lt && std::atoi(lt) > 0 ? (uint32_t)std::atoi(lt) : 16u;
-    P->shade_threshold = sh && std::atoi(sh) > 0 ? (uint32_t)std::atoi(sh) : 16u;
+    P->leaf_threshold = (uint32_t)env_int("RT_AMD_LEAF_THRESHOLD", 16);
+    P->fetch_threshold = (uint32_t)env_int("RT_AMD_FETCH_THRESHOLD", 16);
+    P->regroup = std::getenv("RT_AMD_NO_REGROUP") ? 0u : 1u;
     return RT_OK;
 }
 
@@ -158,6 +156,14 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
         hipError_t e2 = hipMalloc((void**)&s->d_counters, 8 * sizeof(unsigned long long));
         if (e2 != hipSuccess) st = rt_fail(RT_ENOMEM, "hipMalloc failed: %s", hipGetErrorString(e2));
     }
+    if (st == RT_OK) {
+        hipError_t e3 = hipMalloc((void**)&s->d_sync, SYNC_WORDS * sizeof(uint32_t));
+        if (e3 == hipSuccess) e3 = hipHostMalloc((void**)&s->h_sync, SYNC_WORDS * sizeof(uint32_t), hipHostMallocDefault);
+        hipDeviceProp_t prop;
+        if (e3 == hipSuccess) e3 = hipGetDeviceProperties(&prop, device);
+        if (e3 != hipSuccess) st = rt_fail(RT_ENOMEM, "scene scratch allocation failed: %s", hipGetErrorString(e3));
+        else s->n_cus = prop.multiProcessorCount;
+    }
     if (st != RT_OK) { rt_scene_destroy(s); return st; }
     s->dev.n_nodes = (uint32_t)(H.nodes.size() / 2);
     s->dev.n_prims = (uint32_t)(H.prims.size() / 3);
@@ -172,7 +178,10 @@ int rt_scene_destroy(rtScene* s) {
     (void)hipSetDevice(s->device);
     for (int i = 0; i < s->n_buffers; ++i) (void)hipFree(s->buffers[i]);
     if (s->d_pattern) (void)hipFree(s->d_pattern);
-    if (s->d_partial) (void)hipFree(s->d_partial);
+    if (s->d_radiance) (void)hipFree(s->d_radiance);
+    if (s->d_pool) (void)hipFree(s->d_pool);
+    if (s->d_sync) (void)hipFree(s->d_sync);
+    if (s->h_sync) (void)hipHostFree(s->h_sync);
     if (s->d_accum) (void)hipFree(s->d_accum);
     if (s->d_counters) (void)hipFree(s->d_counters);
     delete s;
@@ -192,24 +201,61 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
     HIP_TRY(hipSetDevice(s->device));
     P.sample_first = sample_first;
     P.sample_stride = sample_stride;
-    P.n_shard_samples = (uint32_t)((n - sample_first + sample_stride - 1) / sample_stride);
-    P.n_chunks = pick_chunks(P.tiles_x * P.tiles_y, P.n_shard_samples);
-    if ((uint64_t)P.tiles_x * P.tiles_y * P.n_chunks > 0x3FFFFFFFull) return rt_fail(RT_EINVAL, "launch too large");
+    const uint32_t n_shard_samples = (uint32_t)((n - sample_first + sample_stride - 1) / sample_stride);
+    // Slots in flight: enough rays per launch to fill the machine many times over (default 4 M).
+    PathPool pool;
+    uint64_t total_paths = (uint64_t)P.n_pixels * n_shard_samples;
+    pool.n_slots = (uint32_t)env_int("RT_AMD_SLOTS", 4 * 1024 * 1024);
+    if ((uint64_t)pool.n_slots > total_paths) pool.n_slots = (uint32_t)((total_paths + 1023ull) / 1024ull * 1024ull);
+    // The radiance of every path is kept until its pixel is summed, so the frame is cut into batches of pattern
+    // columns whose radiance buffer fits the budget (default 12 GiB of the 288 GB).
+    uint64_t budget = (uint64_t)env_int("RT_AMD_RADIANCE_MIB", 12 * 1024) * 1024ull * 1024ull;
+    uint64_t cols = budget / ((uint64_t)P.n_pixels * sizeof(float4));
+    uint64_t max_cols = (0xFFFFFFFFull - pool.n_slots - 4096ull) / P.n_pixels; // path numbers are 32-bit
+    if (cols > max_cols) cols = max_cols;
+    if (cols > n_shard_samples) cols = n_shard_samples;
+    if (cols < 1) return rt_fail(RT_EINVAL, "image too large for the radiance buffer budget");
     st = ensure(&s->d_pattern, &s->pattern_cap, (size_t)2 * (size_t)n);
     if (st != RT_OK) return st;
-    st = ensure(&s->d_partial, &s->partial_cap, P.image_floats * P.n_chunks);
+    st = ensure(&s->d_pool, &s->pool_cap, (size_t)5 * pool.n_slots);
     if (st != RT_OK) return st;
+    st = ensure(&s->d_radiance, &s->radiance_cap, (size_t)cols * P.n_pixels);
+    if (st != RT_OK) return st;
+    pool.q = s->d_pool;
     HIP_TRY(hipMemcpyAsync(s->d_pattern, pattern, (size_t)2 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, stream));
     bool count = (flags & RT_FLAG_COUNTERS) != 0;
     if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), stream));
     RtCameraDev cam;
     camera_to_dev(camera, &cam);
-    rt_launch_render(&s->dev, &cam, s->d_pattern, &P, s->d_partial, s->d_counters, count, stream);
-    HIP_TRY(hipGetLastError());
-    rt_launch_reduce(s->d_partial, P.n_chunks, P.image_floats, d_accum, stream);
-    HIP_TRY(hipGetLastError());
+    uint32_t extend_blocks = (uint32_t)(s->n_cus > 0 ? s->n_cus : 256) * (uint32_t)env_int("RT_AMD_EXTEND_BLOCKS_PER_CU", 6);
+    for (uint32_t k0 = 0; k0 < n_shard_samples; k0 += (uint32_t)cols) {
+        P.k_begin = k0;
+        P.k_end = k0 + (uint32_t)cols < n_shard_samples ? k0 + (uint32_t)cols : n_shard_samples;
+        P.n_paths = (P.k_end - P.k_begin) * P.n_pixels;
+        // sync[0] = slot dispenser, sync[1] = next unstarted path, sync[2..] = active slots after each bounce
+        uint32_t init_sync[2] = {0u, pool.n_slots < P.n_paths ? pool.n_slots : P.n_paths};
+        HIP_TRY(hipMemcpyAsync(s->d_sync, init_sync, sizeof(init_sync), hipMemcpyHostToDevice, stream));
+        rt_launch_init(&cam, s->d_pattern, &P, &pool, stream);
+        HIP_TRY(hipGetLastError());
+        // Bounce loop: the device reports after every bounce how many slots still hold a ray; the host enqueues
+        // bounces in batches and stops after the first batch that ends with none.
+        for (uint64_t bounce = 0;; bounce += BOUNCE_BATCH) {
+            HIP_TRY(hipMemsetAsync(s->d_sync + 2, 0, BOUNCE_BATCH * sizeof(uint32_t), stream));
+            for (uint32_t b = 0; b < BOUNCE_BATCH; ++b)
+                rt_launch_bounce(&s->dev, &cam, s->d_pattern, &P, &pool, extend_blocks, s->d_radiance, s->d_sync,
+                                 s->d_sync + 2u + b, s->d_counters, count, stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(s->h_sync, s->d_sync + 1u + BOUNCE_BATCH, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (s->h_sync[0] == 0u) break;
+            if (bounce > ((uint64_t)P.n_paths / pool.n_slots + 2ull) * 64ull + 4096ull)
+                return rt_fail(RT_EHIP, "rt_render_accumulate: bounce loop did not terminate");
+        }
+        rt_launch_sum(&P, s->d_radiance, d_accum, k0 == 0u ? 1 : 0, stream);
+        HIP_TRY(hipGetLastError());
+    }
     s->last_stream = stream;
-    s->last_paths = (uint64_t)width * (uint64_t)height * (uint64_t)P.n_shard_samples;
+    s->last_paths = total_paths;
     return RT_OK;
 }
 

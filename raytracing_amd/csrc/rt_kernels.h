@@ -12,22 +12,35 @@ struct RtCameraDev { // same field order as rtCamera (src/camera.jl:3-14)
     float lens_radius, t0, t1;
 };
 
+struct PathPool { // per-slot path state, six float4 planes of n_slots entries each (see rt_kernels.hip)
+    float4* q;
+    uint32_t n_slots;
+};
+
 struct RtRenderParams {
     int width, height, max_depth;
-    int sample_first, sample_stride; // pattern columns of this shard: sample_first + k*sample_stride
-    uint32_t n_shard_samples;        // number of such columns
-    uint32_t n_chunks;               // waves per pixel tile; chunk c takes k = c, c + n_chunks, ...
-    uint32_t tiles_x, tiles_y;       // 8x8-pixel tiles
+    int sample_first, sample_stride; // shard sample k is pattern column sample_first + k*sample_stride
+    uint32_t k_begin, k_end;         // batch of shard samples rendered by the current bounce loop
+    uint32_t n_pixels;               // width * height
+    uint32_t n_paths;                // (k_end - k_begin) * n_pixels
     uint32_t seed32;
     float background[3];
-    uint32_t leaf_threshold, shade_threshold; // wave vote: run the leaf / shade block once this many lanes wait for it
+    uint32_t leaf_threshold;         // wave vote: test pending leaves once this many lanes hold one
+    uint32_t fetch_threshold;        // extend kernel: refill the wave once this many lanes are idle
+    uint32_t regroup;                // shade kernel: regroup the workgroup's slots by material type
     size_t image_floats;             // 3 * width * height
 };
 
 extern "C" {
-void rt_launch_render(const DevScene* S, const RtCameraDev* cam, const float* d_pattern, const RtRenderParams* P,
-                      float* d_partial, unsigned long long* d_counters, bool count, hipStream_t stream);
-void rt_launch_reduce(const float* d_partial, uint32_t n_chunks, size_t image_floats, float* d_accum, hipStream_t stream);
+void rt_launch_init(const RtCameraDev* cam, const float* d_pattern, const RtRenderParams* P, const PathPool* pool,
+                    hipStream_t stream);
+// one bounce of every slot: extend (closest hits) then shade (scatter / next path).  d_sync[0] is the slot dispenser
+// (zero before the first bounce), d_sync[1] the next unstarted path; *d_active receives the number of slots that still
+// hold a ray after the bounce.
+void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, const float* d_pattern, const RtRenderParams* P,
+                      const PathPool* pool, uint32_t extend_blocks, float4* d_radiance, uint32_t* d_sync, uint32_t* d_active,
+                      unsigned long long* d_counters, bool count, hipStream_t stream);
+void rt_launch_sum(const RtRenderParams* P, const float4* d_radiance, float* d_accum, int first_batch, hipStream_t stream);
 void rt_launch_finalize(const float* d_accum, float inv_n, size_t image_floats, float* d_out, hipStream_t stream);
 void rt_launch_trace_rays(const DevScene* S, const float* d_rays, int n, float t_min, float t_max, uint32_t seed32,
                           int32_t* prim_id, int32_t* sub_id, float* t, float* normal, float* uv, uint8_t* front,

@@ -704,19 +704,17 @@ struct PathState {
     int depth;
 };
 
-// The body of the while loop of trace() after hit(scene, ray) returned (the finished walker W holds the ray and
-// its closest hit).  Returns true when the path ended, with its radiance in `result`; otherwise W is restarted
-// on the scattered ray.
-__device__ __forceinline__ bool shade(const DevScene& S, Walker& W, PathState& ps, f3 background, RngKey& key, f3& result) {
-    if (W.best.t == INF) { result = ps.color + ps.acc * background; return true; }
-    f3 o = W.inst_xf ? W.so : W.o, d = W.inst_xf ? W.sd : W.d; // (a finished walker is always back in the outer frame)
+// The body of the while loop of trace() after hit(scene, ray) returned `best` for the ray (o, d, time).
+// Returns true when the path ended, with its radiance in `result`; otherwise (no, nd) is the scattered ray.
+__device__ __forceinline__ bool shade(const DevScene& S, f3 o, f3 d, float time, const Closest& best, PathState& ps,
+                                      f3 background, RngKey& key, f3& result, f3& no, f3& nd) {
+    if (best.t == INF) { result = ps.color + ps.acc * background; return true; }
     HitRec h;
-    complete_hit<false>(S, o, d, W.time, W.best, h);
+    complete_hit<false>(S, o, d, time, best, h);
     uint4 m = S.materials[h.material];
     uint32_t type = m.x & 0xFFu;
     f3 att;
     f3 emitted = mk3(0.0f, 0.0f, 0.0f);
-    f3 nd;
     if (type == 1u) { // Lambertian
         nd = h.n + normalize3(random_in_unit_sphere(key));
         if (is_zero3(nd)) nd = h.n;
@@ -749,7 +747,7 @@ __device__ __forceinline__ bool shade(const DevScene& S, Walker& W, PathState& p
     ps.depth -= 1;
     key.bounce += 1;
     if (ps.depth <= 0) { result = ps.color; return true; }
-    walker_start(W, S, h.p, nd, W.time, 0.001f, INF);
+    no = h.p;
     return false;
 }
 
@@ -772,98 +770,260 @@ __device__ __forceinline__ void camera_ray(const RtCameraDev& cam, const float* 
 }
 
 // ------------------------------------------------------------------ kernels
-// Work decomposition: the image is cut into 8x8-pixel tiles, one wave per (tile, chunk); lane l owns pixel
-// (l & 7, l >> 3) of the tile and sums its chunk's pattern columns in order.  Chunks exist only to expose more
-// waves than pixels/64; partial sums go to partial[chunk][pixel] and are added up in chunk order by
-// rt_reduce_kernel, so the result does not depend on scheduling.
-template <bool COUNT>
-__global__ void __launch_bounds__(256) rt_render_kernel(DevScene S, RtCameraDev cam, const float* __restrict__ pattern,
-                                                        RtRenderParams P, float* __restrict__ partial,
-                                                        unsigned long long* __restrict__ counters) {
-    uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    uint32_t lane = threadIdx.x & 63u;
-    uint32_t n_tiles = P.tiles_x * P.tiles_y;
-    uint32_t chunk = wave / n_tiles;
-    uint32_t tile = wave - chunk * n_tiles;
-    if (chunk >= P.n_chunks) return;
-    int i = (int)((tile % P.tiles_x) * 8u + (lane & 7u));
-    int j = (int)((tile / P.tiles_x) * 8u + (lane >> 3));
-    if (i >= P.width || j >= P.height) return;
-    Counters cnt = {0, 0, 0, 0, 0, 0};
-    RngKey key;
-    key.pixel = (uint32_t)j * (uint32_t)P.width + (uint32_t)i;
+// The frame is rendered wavefront style.  A *path* is one trace() call: pattern column k of pixel r (r = row-
+// major pixel index, j * width + i, j counted from the bottom like the loops of draw!).  Paths are numbered
+// p = (k - k_begin) * n_pixels + r inside the batch of columns [k_begin, k_end) being rendered.  A pool of
+// *slots* (PathPool, six float4 planes in HBM) holds the paths in flight; every bounce is two launches:
+//   rt_extend_kernel  closest hit of every slot's ray (persistent waves; a lane fetches the next slot as soon as
+//                     its ray is finished; node stepping and leaf tests run under a wave-wide vote)
+//   rt_shade_kernel   hit completion, emission, scatter; a slot whose path ended writes the path's radiance to
+//                     radiance[p] and takes the next unstarted path.  The 1024 slots of a workgroup are regrouped
+//                     by material type in LDS so that a wave shades one material.
+// rt_sum_kernel then adds each pixel's radiances in column order, the order of the sample loop of draw!
+// (src/Ray_Tracing.jl:82-89), so the image does not depend on scheduling.
+// plane 0: {origin, time}        plane 1: {direction, bits(depth)}   depth <= 0: the slot holds no ray
+// plane 2: {acc, bits(p)}        plane 3: {color, -}
+// plane 4: {t, bits(prim), bits(side|xform), bits(type)}   type: 1..5 material type of the hit, 6 = miss
+#define QP(pool, plane, slot) (pool).q[(size_t)(plane) * (pool).n_slots + (slot)]
+#define HIT_MISS 6u
+#define EXTEND_CHUNK 256u
+
+// path p -> pixel (i, j), pattern column n; fills the random-number key of the path
+__device__ __forceinline__ void path_ident(const RtRenderParams& P, uint32_t p, int& i, int& j, int& n, RngKey& key) {
+    uint32_t kk = p / P.n_pixels;
+    uint32_t r = p - kk * P.n_pixels;
+    j = (int)(r / (uint32_t)P.width);
+    i = (int)(r - (uint32_t)j * (uint32_t)P.width);
+    n = P.sample_first + (int)(P.k_begin + kk) * P.sample_stride;
+    key.pixel = r;
+    key.sample = (uint32_t)n;
     key.seed32 = P.seed32;
-    f3 bg = mk3(P.background[0], P.background[1], P.background[2]);
-    f3 col = mk3(0.0f, 0.0f, 0.0f);
-    // Shard sample k is pattern column sample_first + k*sample_stride; this chunk takes k = chunk, chunk + n_chunks, ...
-    // Every lane adds its paths in column order, exactly like the sample loop of draw! (src/Ray_Tracing.jl:82-89).
-    //
-    // The wave runs a voted state machine: each lane is either stepping through BVH nodes, holding a leaf to
-    // test, or holding a finished ray to shade (after which it continues its path or starts its next column at
-    // once).  Per iteration the wave executes the block chosen by wave_vote() for the lanes waiting for it.
-    uint32_t k = chunk;
-    bool alive = k < P.n_shard_samples;
-    PathState ps;
+}
+
+// camera ray of path p into slot `slot`
+__device__ __forceinline__ void start_path(const RtCameraDev& cam, const float* pattern, const RtRenderParams& P,
+                                           PathPool& pool, uint32_t slot, uint32_t p) {
+    int i, j, n;
+    RngKey key;
+    path_ident(P, p, i, j, n, key);
+    f3 o, d;
+    float time;
+    camera_ray(cam, pattern, i, j, n, P.width, P.height, key, o, d, time);
+    QP(pool, 0, slot) = make_float4(o.x, o.y, o.z, time);
+    QP(pool, 1, slot) = make_float4(d.x, d.y, d.z, __uint_as_float((uint32_t)P.max_depth));
+    QP(pool, 2, slot) = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(p));
+    QP(pool, 3, slot) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// the first n_slots paths of the batch; sync[0] = slot dispenser, sync[1] = next unstarted path
+__global__ void __launch_bounds__(256) rt_init_kernel(RtCameraDev cam, const float* __restrict__ pattern, RtRenderParams P,
+                                                      PathPool pool) {
+    uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= pool.n_slots) return;
+    float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    QP(pool, 4, slot) = z;
+    if (slot < P.n_paths && P.max_depth > 0) {
+        start_path(cam, pattern, P, pool, slot, slot);
+    } else {
+        QP(pool, 0, slot) = z;
+        QP(pool, 1, slot) = z; // depth 0: no ray
+        QP(pool, 2, slot) = z;
+        QP(pool, 3, slot) = z;
+    }
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256) rt_extend_kernel(DevScene S, RtRenderParams P, PathPool pool, uint32_t* __restrict__ head,
+                                                        unsigned long long* __restrict__ counters) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool media = S.medium_root != RT_NODE_END;
+    Counters cnt = {0, 0, 0, 0, 0, 0};
+    uint32_t cur = 0, end = 0; // wave-uniform cursor into the chunk of slots this wave owns
+    bool exhausted = false;
+    bool busy = false;
+    uint32_t slot = 0;
+    RngKey key = {0u, 0u, P.seed32, 0u};
     Walker W;
-    Vote V = {P.leaf_threshold, P.shade_threshold};
-    auto start_path = [&]() {
-        int n = P.sample_first + (int)k * P.sample_stride;
-        key.sample = (uint32_t)n;
-        f3 o, d;
-        float time;
-        camera_ray(cam, pattern, i, j, n, P.width, P.height, key, o, d, time);
-        ps.acc = mk3(1.0f, 1.0f, 1.0f);
-        ps.color = mk3(0.0f, 0.0f, 0.0f);
-        ps.depth = P.max_depth;
-        key.bounce = 0;
-        walker_start(W, S, o, d, time, 0.001f, INF);
-        if (COUNT) cnt.rays++;
-    };
     walker_start(W, S, mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 1.0f), 0.0f, 0.001f, INF);
-    if (alive) start_path();
     for (;;) {
-        bool ws = alive && walker_wants_step(W), wl = alive && walker_wants_leaf(W), wh = alive && walker_finished(W);
-        int block = wave_vote(ws, wl, wh, V);
-        if (block == 3) break;
-        if (block == 0) {
-            if (ws) { if (COUNT) cnt.node_waves += first_active_lane(); walker_step<COUNT>(W, S, cnt); }
-        } else if (block == 1) {
+        bool ws = busy && walker_wants_step(W), wl = busy && walker_wants_leaf(W);
+        bool fin = busy && walker_finished(W);
+        uint32_t n_need = (uint32_t)__popcll(__ballot(!busy || fin));
+        bool any_work = __ballot(ws || wl) != 0ull;
+        if ((n_need >= P.fetch_threshold && !exhausted) || !any_work) {
+            if (fin) { // retire: publish the hit for the shade kernel
+                uint32_t type = HIT_MISS;
+                if (W.best.t != INF) type = S.materials[S.prims[3u * W.best.prim].y].x & 0xFFu;
+                QP(pool, 4, slot) = make_float4(W.best.t, __uint_as_float(W.best.prim), __uint_as_float(W.best.sx), __uint_as_float(type));
+                if (COUNT) cnt.rays++;
+                busy = false;
+            }
+            if (!exhausted) {
+                unsigned long long m = __ballot(!busy);
+                if (cur >= end) { // take the next chunk of slots
+                    uint32_t base = 0;
+                    if (lane == 0u) base = atomicAdd(head, EXTEND_CHUNK);
+                    base = (uint32_t)__shfl((int)base, 0);
+                    if (base >= pool.n_slots) { exhausted = true; cur = end = 0; }
+                    else { cur = base; end = min(base + EXTEND_CHUNK, pool.n_slots); }
+                }
+                if (!exhausted) {
+                    if (!busy) {
+                        uint32_t sidx = cur + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        if (sidx < end) {
+                            float4 q1 = QP(pool, 1, sidx);
+                            int depth = (int)__float_as_uint(q1.w);
+                            if (depth > 0) {
+                                float4 q0 = QP(pool, 0, sidx);
+                                slot = sidx;
+                                busy = true;
+                                walker_start(W, S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, 0.001f, INF);
+                                if (media) { // the medium test draws a random number keyed by the path
+                                    int i, j, n;
+                                    path_ident(P, __float_as_uint(QP(pool, 2, sidx).w), i, j, n, key);
+                                    key.bounce = (uint32_t)(P.max_depth - depth);
+                                }
+                            }
+                        }
+                    }
+                    cur = min(cur + (uint32_t)__popcll(m), end);
+                }
+            }
+            if (exhausted && __ballot(busy) == 0ull) break;
+            continue;
+        }
+        uint32_t nl = (uint32_t)__popcll(__ballot(wl));
+        uint32_t ns = (uint32_t)__popcll(__ballot(ws));
+        if (nl >= P.leaf_threshold || ns == 0u) {
             if (wl) { if (COUNT) cnt.prim_waves += first_active_lane(); walker_leaf<COUNT>(W, S, key, cnt); }
-        } else if (wh) {
-            if (COUNT) cnt.bounce_waves += first_active_lane();
-            f3 result;
-            bool done = ps.depth <= 0;
-            if (done) result = ps.color;
-            else done = shade(S, W, ps, bg, key, result);
-            if (done) {
-                col = col + result;
-                k += P.n_chunks;
-                alive = k < P.n_shard_samples;
-                if (alive) start_path();
-            } else if (COUNT) cnt.rays++;
+        } else {
+            if (ws) { if (COUNT) cnt.node_waves += first_active_lane(); walker_step<COUNT>(W, S, cnt); }
         }
     }
-    size_t idx = ((size_t)i * (size_t)P.height + (size_t)(P.height - 1 - j)) * 3u; // img[height-j, i+1]
-    float* dst = partial + (size_t)chunk * P.image_floats + idx;
-    dst[0] = col.x; dst[1] = col.y; dst[2] = col.z;
     if (COUNT) {
         atomicAdd(&counters[0], (unsigned long long)cnt.rays);
         atomicAdd(&counters[1], (unsigned long long)cnt.nodes);
         atomicAdd(&counters[2], (unsigned long long)cnt.prims);
         atomicAdd(&counters[3], (unsigned long long)cnt.node_waves);
         atomicAdd(&counters[4], (unsigned long long)cnt.prim_waves);
-        atomicAdd(&counters[5], (unsigned long long)cnt.bounce_waves);
     }
 }
 
-// accum[i] = sum over chunks, in chunk order
-__global__ void __launch_bounds__(256) rt_reduce_kernel(const float* __restrict__ partial, uint32_t n_chunks,
-                                                        size_t image_floats, float* __restrict__ accum) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= image_floats) return;
-    float s = partial[i];
-    for (uint32_t c = 1; c < n_chunks; ++c) s = s + partial[(size_t)c * image_floats + i];
-    accum[i] = s;
+#define SHADE_BLOCK 1024
+// sync[0]: slot dispenser of rt_extend_kernel (reset here), sync[1]: next unstarted path, active: slots holding a
+// ray after this bounce
+__global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCameraDev cam, const float* __restrict__ pattern,
+                                                               RtRenderParams P, PathPool pool, float4* __restrict__ radiance,
+                                                               uint32_t* __restrict__ sync, uint32_t* __restrict__ active) {
+    __shared__ uint32_t hist[8], cursor[8];
+    __shared__ uint16_t order[SHADE_BLOCK];
+    __shared__ uint32_t block_alive, block_need, block_base;
+    const uint32_t t = threadIdx.x;
+    const uint32_t base = blockIdx.x * SHADE_BLOCK;
+    if (t < 8u) { hist[t] = 0u; }
+    if (t == 0u) { block_alive = 0u; block_need = 0u; }
+    if (blockIdx.x == 0 && t == 0u) sync[0] = 0u; // re-arm the slot dispenser of the next rt_extend_kernel
+    __syncthreads();
+    // material type of the slot this thread sits on; 7 = nothing to shade
+    uint32_t my_key = 7u;
+    if (base + t < pool.n_slots) {
+        int depth0 = (int)__float_as_uint(QP(pool, 1, base + t).w);
+        if (depth0 > 0) my_key = __float_as_uint(QP(pool, 4, base + t).w) & 7u;
+    }
+    uint32_t mine = t;
+    if (P.regroup) {
+        // counting sort of the block's slots by material type: afterwards thread t shades slot order[t], and
+        // the threads of a wave (almost always) hold the same material
+        atomicAdd(&hist[my_key], 1u);
+        __syncthreads();
+        if (t == 0u) {
+            uint32_t acc = 0u;
+            for (int q = 0; q < 8; ++q) { cursor[q] = acc; acc += hist[q]; }
+        }
+        __syncthreads();
+        uint32_t pos = atomicAdd(&cursor[my_key], 1u);
+        order[pos] = (uint16_t)t;
+        __syncthreads();
+        mine = order[t];
+    }
+    uint32_t slot = base + mine;
+    bool valid = slot < pool.n_slots;
+    float4 q1 = valid ? QP(pool, 1, slot) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int depth = (int)__float_as_uint(q1.w);
+    bool done = false, cont = false;
+    if (valid && depth > 0) {
+        float4 q0 = QP(pool, 0, slot), q2 = QP(pool, 2, slot), q3 = QP(pool, 3, slot), q4 = QP(pool, 4, slot);
+        uint32_t p = __float_as_uint(q2.w);
+        int i, j, n;
+        RngKey key;
+        path_ident(P, p, i, j, n, key);
+        key.bounce = (uint32_t)(P.max_depth - depth);
+        PathState ps;
+        ps.acc = mk3(q2.x, q2.y, q2.z);
+        ps.color = mk3(q3.x, q3.y, q3.z);
+        ps.depth = depth;
+        Closest best;
+        best.t = q4.x; best.prim = __float_as_uint(q4.y); best.sx = __float_as_uint(q4.z); best.rank = 0u;
+        f3 result, no, nd;
+        done = shade(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, best, ps,
+                     mk3(P.background[0], P.background[1], P.background[2]), key, result, no, nd);
+        if (done) {
+            radiance[p] = make_float4(result.x, result.y, result.z, 0.0f);
+        } else {
+            cont = true;
+            QP(pool, 0, slot) = make_float4(no.x, no.y, no.z, q0.w);
+            QP(pool, 1, slot) = make_float4(nd.x, nd.y, nd.z, __uint_as_float((uint32_t)ps.depth));
+            QP(pool, 2, slot) = make_float4(ps.acc.x, ps.acc.y, ps.acc.z, q2.w);
+            QP(pool, 3, slot) = make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f);
+        }
+    }
+    // slots whose path ended take the next unstarted paths: one atomic per workgroup
+    unsigned long long m_done = __ballot(done);
+    uint32_t wave_pos = 0u;
+    if (m_done) {
+        if ((t & 63u) == 0u) wave_pos = atomicAdd(&block_need, (uint32_t)__popcll(m_done));
+        wave_pos = (uint32_t)__shfl((int)wave_pos, 0);
+    }
+    __syncthreads();
+    if (t == 0u) {
+        // once every path of the batch has been handed out the counter is left alone, so it cannot wrap
+        block_base = 0xFFFFFFFFu;
+        if (block_need && __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P.n_paths)
+            block_base = atomicAdd(&sync[1], block_need);
+    }
+    __syncthreads();
+    if (done) {
+        uint32_t p = block_base + wave_pos + (uint32_t)__popcll(m_done & ((1ull << (t & 63u)) - 1ull));
+        if (block_base != 0xFFFFFFFFu && p < P.n_paths) {
+            start_path(cam, pattern, P, pool, slot, p);
+            cont = true;
+        } else {
+            QP(pool, 1, slot) = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // no ray left for this slot
+        }
+    }
+    // number of slots that still hold a ray: the host stops launching bounces when it reaches zero
+    unsigned long long m = __ballot(cont);
+    if ((t & 63u) == 0u && m) atomicAdd(&block_alive, (uint32_t)__popcll(m));
+    __syncthreads();
+    if (t == 0u && block_alive) atomicAdd(active, block_alive);
+}
+
+// accum[pixel] (+)= radiance of the pixel's paths of this batch, added in column order like the sample loop of draw!
+// (src/Ray_Tracing.jl:82-89); accum is in the Julia image layout img[height-j, i+1]
+__global__ void __launch_bounds__(256) rt_sum_kernel(RtRenderParams P, const float4* __restrict__ radiance,
+                                                     float* __restrict__ accum, int first_batch) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= P.n_pixels) return;
+    int j = (int)(r / (uint32_t)P.width);
+    int i = (int)(r - (uint32_t)j * (uint32_t)P.width);
+    size_t idx = ((size_t)i * (size_t)P.height + (size_t)(P.height - 1 - j)) * 3u;
+    f3 col = first_batch ? mk3(0.0f, 0.0f, 0.0f) : mk3(accum[idx], accum[idx + 1], accum[idx + 2]);
+    uint32_t nk = P.k_end - P.k_begin;
+    for (uint32_t kk = 0; kk < nk; ++kk) {
+        float4 v = radiance[(size_t)kk * P.n_pixels + r];
+        col = col + mk3(v.x, v.y, v.z);
+    }
+    accum[idx] = col.x; accum[idx + 1] = col.y; accum[idx + 2] = col.z;
 }
 
 // col /= N; sqrt per channel (src/Ray_Tracing.jl:90-91,152-153; the division is a multiply by Float32(1/N))
@@ -930,7 +1090,7 @@ __global__ void __launch_bounds__(256) rt_trace_paths_kernel(DevScene S, RtCamer
     f3 bgc = mk3(P.background[0], P.background[1], P.background[2]);
     Walker W;
     walker_start(W, S, o, d, time, 0.001f, INF);
-    Vote V = {P.leaf_threshold, P.shade_threshold};
+    Vote V = {P.leaf_threshold, 16u};
     for (;;) {
         bool ws = alive && walker_wants_step(W), wl = alive && walker_wants_leaf(W), wh = alive && walker_finished(W);
         int block = wave_vote(ws, wl, wh, V);
@@ -939,9 +1099,11 @@ __global__ void __launch_bounds__(256) rt_trace_paths_kernel(DevScene S, RtCamer
         else if (block == 1) { if (wl) walker_leaf<false>(W, S, key, cnt); }
         else if (wh) {
             bool done = ps.depth <= 0;
+            f3 no, nd;
             if (done) c = ps.color;
-            else done = shade(S, W, ps, bgc, key, c);
+            else done = shade(S, W.o, W.d, W.time, W.best, ps, bgc, key, c, no, nd);
             if (done) alive = false;
+            else walker_start(W, S, no, nd, W.time, 0.001f, INF);
         }
     }
     if (k >= n_paths || blockIdx.x * blockDim.x + threadIdx.x >= (unsigned)n_paths) return;
@@ -949,16 +1111,21 @@ __global__ void __launch_bounds__(256) rt_trace_paths_kernel(DevScene S, RtCamer
 }
 
 // ------------------------------------------------------------------ host-callable launchers
-extern "C" void rt_launch_render(const DevScene* S, const RtCameraDev* cam, const float* d_pattern, const RtRenderParams* P,
-                                 float* d_partial, unsigned long long* d_counters, bool count, hipStream_t stream) {
-    uint32_t waves = P->tiles_x * P->tiles_y * P->n_chunks;
-    uint32_t blocks = (waves + 3u) / 4u;
-    if (count) hipLaunchKernelGGL(rt_render_kernel<true>, dim3(blocks), dim3(256), 0, stream, *S, *cam, d_pattern, *P, d_partial, d_counters);
-    else hipLaunchKernelGGL(rt_render_kernel<false>, dim3(blocks), dim3(256), 0, stream, *S, *cam, d_pattern, *P, d_partial, d_counters);
+extern "C" void rt_launch_init(const RtCameraDev* cam, const float* d_pattern, const RtRenderParams* P, const PathPool* pool,
+                               hipStream_t stream) {
+    hipLaunchKernelGGL(rt_init_kernel, dim3((pool->n_slots + 255u) / 256u), dim3(256), 0, stream, *cam, d_pattern, *P, *pool);
 }
-extern "C" void rt_launch_reduce(const float* d_partial, uint32_t n_chunks, size_t image_floats, float* d_accum, hipStream_t stream) {
-    uint32_t blocks = (uint32_t)((image_floats + 255) / 256);
-    hipLaunchKernelGGL(rt_reduce_kernel, dim3(blocks), dim3(256), 0, stream, d_partial, n_chunks, image_floats, d_accum);
+extern "C" void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, const float* d_pattern, const RtRenderParams* P,
+                                 const PathPool* pool, uint32_t extend_blocks, float4* d_radiance, uint32_t* d_sync,
+                                 uint32_t* d_active, unsigned long long* d_counters, bool count, hipStream_t stream) {
+    uint32_t shade_blocks = (pool->n_slots + SHADE_BLOCK - 1u) / SHADE_BLOCK;
+    if (count) hipLaunchKernelGGL(rt_extend_kernel<true>, dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    else hipLaunchKernelGGL(rt_extend_kernel<false>, dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    hipLaunchKernelGGL(rt_shade_kernel, dim3(shade_blocks), dim3(SHADE_BLOCK), 0, stream, *S, *cam, d_pattern, *P, *pool, d_radiance,
+                       d_sync, d_active);
+}
+extern "C" void rt_launch_sum(const RtRenderParams* P, const float4* d_radiance, float* d_accum, int first_batch, hipStream_t stream) {
+    hipLaunchKernelGGL(rt_sum_kernel, dim3((P->n_pixels + 255u) / 256u), dim3(256), 0, stream, *P, d_radiance, d_accum, first_batch);
 }
 extern "C" void rt_launch_finalize(const float* d_accum, float inv_n, size_t image_floats, float* d_out, hipStream_t stream) {
     uint32_t blocks = (uint32_t)((image_floats + 255) / 256);
