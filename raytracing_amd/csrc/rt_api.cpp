@@ -102,6 +102,7 @@ int fill_params(const float background[3], int width, int height, int max_depth,
     P->image_floats = (size_t)3 * (size_t)width * (size_t)height;
     P->leaf_threshold = (uint32_t)env_int("RT_AMD_LEAF_THRESHOLD", 16);
     P->fetch_threshold = (uint32_t)env_int("RT_AMD_FETCH_THRESHOLD", 16);
+    P->step_dropout = (uint32_t)env_int("RT_AMD_STEP_DROPOUT", 8);
     P->regroup = std::getenv("RT_AMD_NO_REGROUP") ? 0u : 1u;
     return RT_OK;
 }

@@ -27,6 +27,7 @@ struct RtRenderParams {
     float background[3];
     uint32_t leaf_threshold;         // wave vote: test pending leaves once this many lanes hold one
     uint32_t fetch_threshold;        // extend kernel: refill the wave once this many lanes are idle
+    uint32_t step_dropout;           // extend kernel: leave the node-stepping loop after this many lanes dropped out
     uint32_t regroup;                // shade kernel: regroup the workgroup's slots by material type
     size_t image_floats;             // 3 * width * height
 };

@@ -345,6 +345,57 @@ __device__ __forceinline__ void consider(Walker& W, float t, uint32_t prim, uint
     }
 }
 
+// The two boundary probes of src/constant_medium.jl:30-35, hit(boundary, r, -Inf, Inf).t and
+// hit(boundary, r, t1 + 0.0001, Inf).t, from ONE evaluation of the boundary: every candidate distance is computed
+// with the same arithmetic as the shape's own hit function, then the two acceptance windows are applied.
+__device__ __forceinline__ void sphere_probe(f3 center, float radius, f3 o, f3 d, float& t1, float& t2) {
+    // src/sphere.jl:45-65 with (t_min, t_max) = (-Inf, Inf) and then (t1 + 0.0001, Inf)
+    t1 = INF; t2 = INF;
+    f3 oc = o - center;
+    float a = dot3(d, d);
+    float half_b = dot3(oc, d);
+    float c = dot3(oc, oc) - radius * radius;
+    float disc = half_b * half_b - a * c;
+    if (disc < 0.0f) return;
+    float sqrtd = sqrtf(disc);
+    float near_root = (-half_b - sqrtd), far_root = (-half_b + sqrtd);
+    // first probe: the window is (-Inf * a, Inf * a); for a > 0 the near root always passes
+    float lo = -INF * a, hi = INF * a;
+    float root = near_root;
+    if (root < lo || hi < root) {
+        root = far_root;
+        if (root < lo || hi < root) return;
+    }
+    t1 = root / a;
+    // second probe
+    float lo2 = (t1 + 0.0001f) * a;
+    root = near_root;
+    if (root < lo2 || hi < root) {
+        root = far_root;
+        if (root < lo2 || hi < root) return;
+    }
+    t2 = root / a;
+}
+__device__ __forceinline__ void box_probe(const float* g, f3 o, f3 d, float& t1, float& t2) {
+    // src/box.jl:43-83 over the six sides (src/aarect.jl:49-95) for the two windows; the minimum over the
+    // accepted sides does not depend on the order in which box.jl visits them
+    float ts[6];
+    ts[0] = rect_t(o.z, d.z, o.x, d.x, o.y, d.y, g[0], g[3], g[1], g[4], g[5], -INF, INF);
+    ts[1] = rect_t(o.z, d.z, o.x, d.x, o.y, d.y, g[0], g[3], g[1], g[4], g[2], -INF, INF);
+    ts[2] = rect_t(o.y, d.y, o.x, d.x, o.z, d.z, g[0], g[3], g[2], g[5], g[4], -INF, INF);
+    ts[3] = rect_t(o.y, d.y, o.x, d.x, o.z, d.z, g[0], g[3], g[2], g[5], g[1], -INF, INF);
+    ts[4] = rect_t(o.x, d.x, o.y, d.y, o.z, d.z, g[1], g[4], g[2], g[5], g[3], -INF, INF);
+    ts[5] = rect_t(o.x, d.x, o.y, d.y, o.z, d.z, g[1], g[4], g[2], g[5], g[0], -INF, INF);
+    t1 = INF;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) if (ts[q] < t1) t1 = ts[q];
+    t2 = INF;
+    if (t1 == INF) return;
+    float lo2 = t1 + 0.0001f;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) if (!(ts[q] < lo2) && ts[q] < t2) t2 = ts[q];
+}
+
 // src/constant_medium.jl:29-65 for one medium primitive
 __device__ __forceinline__ float medium_t(const DevScene& S, uint32_t head, const float* g, f3 o, f3 d, float time,
                                           float t_min, float t_max, const RngKey& key) {
@@ -355,10 +406,10 @@ __device__ __forceinline__ float medium_t(const DevScene& S, uint32_t head, cons
         ro = apply_point(T, o);
         rd = apply_vec(T, d);
     }
-    uint32_t s2;
-    float t1 = shape_t(kind, g, ro, rd, time, -INF, INF, s2);
+    float t1, t2;
+    if (kind == DP_SPHERE) sphere_probe(mk3(g[0], g[1], g[2]), g[3], ro, rd, t1, t2);
+    else box_probe(g, ro, rd, t1, t2);
     if (t1 == INF) return INF;
-    float t2 = shape_t(kind, g, ro, rd, time, t1 + 0.0001f, INF, s2);
     if (t2 == INF) return INF;
     if (t1 < t_min) t1 = t_min;
     if (t2 > t_max) t2 = t_max;
@@ -372,9 +423,8 @@ __device__ __forceinline__ float medium_t(const DevScene& S, uint32_t head, cons
     return t1 + hit_distance / ray_length;
 }
 
-// One node: region bookkeeping, then fetch + box test.  Call only for lanes with walker_wants_step().
-template <bool COUNT>
-__device__ __forceinline__ void walker_step(Walker& W, const DevScene& S, Counters& cnt) {
+// Region bookkeeping for a lane that ran off the end of a tree (leaf == 0 and node >= RT_NODE_END_SUB).
+__device__ __forceinline__ void walker_transition(Walker& W, const DevScene& S) {
     if (W.node == RT_NODE_END_SUB) { // end of a nested tree: back to the outer ray
         W.o = W.so; W.d = W.sd;
         W.inv = mk3(1.0f / W.d.x, 1.0f / W.d.y, 1.0f / W.d.z);
@@ -385,23 +435,34 @@ __device__ __forceinline__ void walker_step(Walker& W, const DevScene& S, Counte
         W.node = S.medium_root;
         W.in_media = 1u;
     }
+}
+
+// One node: fetch + box test.  Call only for lanes with leaf == 0 and node < RT_NODE_END_SUB.
+__device__ __forceinline__ void node_step(const DevScene& S, const f3& o, const f3& inv, float t_min, float t_max,
+                                          uint32_t& node, uint32_t& leaf) {
+    float4 q0 = S.nodes[2u * node], q1 = S.nodes[2u * node + 1u];
+    // Box test (src/bounding_box.jl:70-84 form).  It only culls: the far distance is widened by 8 ulp so
+    // that rounding can never reject a box that the exact slab test of src/bounding_box.jl:20-67 accepts;
+    // NaNs (0 * Inf) drop out of fminf/fmaxf, which keeps the axis unconstrained.
+    float tx0 = (q0.x - o.x) * inv.x, tx1 = (q1.x - o.x) * inv.x;
+    float ty0 = (q0.y - o.y) * inv.y, ty1 = (q1.y - o.y) * inv.y;
+    float tz0 = (q0.z - o.z) * inv.z, tz1 = (q1.z - o.z) * inv.z;
+    float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t_min));
+    float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), t_max));
+    tfar = __builtin_fmaf(fabsf(tfar), 4.8e-7f, tfar);
+    uint32_t skip = __float_as_uint(q0.w);
+    uint32_t lf = __float_as_uint(q1.w);
+    bool hit = tnear <= tfar;
+    node = (hit && lf == 0u) ? node + 1u : skip;
+    leaf = hit ? lf : 0u;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void walker_step(Walker& W, const DevScene& S, Counters& cnt) {
+    walker_transition(W, S);
     if (W.node < RT_NODE_END_SUB) {
-        float4 q0 = S.nodes[2u * W.node], q1 = S.nodes[2u * W.node + 1u];
         if (COUNT) cnt.nodes++;
-        // Box test (src/bounding_box.jl:70-84 form).  It only culls: the far distance is widened by 8 ulp so
-        // that rounding can never reject a box that the exact slab test of src/bounding_box.jl:20-67 accepts;
-        // NaNs (0 * Inf) drop out of fminf/fmaxf, which keeps the axis unconstrained.
-        float tx0 = (q0.x - W.o.x) * W.inv.x, tx1 = (q1.x - W.o.x) * W.inv.x;
-        float ty0 = (q0.y - W.o.y) * W.inv.y, ty1 = (q1.y - W.o.y) * W.inv.y;
-        float tz0 = (q0.z - W.o.z) * W.inv.z, tz1 = (q1.z - W.o.z) * W.inv.z;
-        float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), W.t_min));
-        float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), W.t_max));
-        tfar = __builtin_fmaf(fabsf(tfar), 4.8e-7f, tfar);
-        uint32_t skip = __float_as_uint(q0.w);
-        uint32_t lf = __float_as_uint(q1.w);
-        bool hit = tnear <= tfar;
-        W.node = (hit && lf == 0u) ? W.node + 1u : skip;
-        W.leaf = hit ? lf : 0u;
+        node_step(S, W.o, W.inv, W.t_min, W.t_max, W.node, W.leaf);
     }
 }
 
@@ -846,12 +907,18 @@ __global__ void __launch_bounds__(256) rt_extend_kernel(DevScene S, RtRenderPara
     Walker W;
     walker_start(W, S, mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 1.0f), 0.0f, 0.001f, INF);
     for (;;) {
-        bool ws = busy && walker_wants_step(W), wl = busy && walker_wants_leaf(W);
+        // ---- lanes that ran off a tree: next region / back out of a nested tree (cheap, no vote needed)
+        if (busy && W.leaf == 0u && W.node >= RT_NODE_END_SUB && !walker_finished(W)) walker_transition(W, S);
+
+        // ---- retire finished rays and fetch new ones once enough lanes are idle
         bool fin = busy && walker_finished(W);
+        bool wl = busy && W.leaf != 0u;
+        bool ws = busy && W.leaf == 0u && W.node < RT_NODE_END_SUB;
         uint32_t n_need = (uint32_t)__popcll(__ballot(!busy || fin));
-        bool any_work = __ballot(ws || wl) != 0ull;
-        if ((n_need >= P.fetch_threshold && !exhausted) || !any_work) {
-            if (fin) { // retire: publish the hit for the shade kernel
+        uint32_t nl = (uint32_t)__popcll(__ballot(wl));
+        uint32_t ns = (uint32_t)__popcll(__ballot(ws));
+        if ((n_need >= P.fetch_threshold && !exhausted) || (nl | ns) == 0u) {
+            if (fin) { // publish the hit for the shade kernel
                 uint32_t type = HIT_MISS;
                 if (W.best.t != INF) type = S.materials[S.prims[3u * W.best.prim].y].x & 0xFFu;
                 QP(pool, 4, slot) = make_float4(W.best.t, __uint_as_float(W.best.prim), __uint_as_float(W.best.sx), __uint_as_float(type));
@@ -892,12 +959,28 @@ __global__ void __launch_bounds__(256) rt_extend_kernel(DevScene S, RtRenderPara
             if (exhausted && __ballot(busy) == 0ull) break;
             continue;
         }
-        uint32_t nl = (uint32_t)__popcll(__ballot(wl));
-        uint32_t ns = (uint32_t)__popcll(__ballot(ws));
+
+        // ---- pending leaves, once enough lanes hold one (or nobody can step)
         if (nl >= P.leaf_threshold || ns == 0u) {
             if (wl) { if (COUNT) cnt.prim_waves += first_active_lane(); walker_leaf<COUNT>(W, S, key, cnt); }
-        } else {
-            if (ws) { if (COUNT) cnt.node_waves += first_active_lane(); walker_step<COUNT>(W, S, cnt); }
+            continue;
+        }
+
+        // ---- hot loop: step through nodes until `step_dropout` more lanes have left it
+        {
+            uint32_t node = W.node, leaf = 0u;
+            const f3 o = W.o, inv = W.inv;
+            const float t_min = W.t_min, t_max = W.t_max;
+            const uint32_t floor_lanes = ns > P.step_dropout ? ns - P.step_dropout : 1u;
+            bool stepping = ws;
+            do {
+                if (stepping) {
+                    if (COUNT) { cnt.nodes++; cnt.node_waves += first_active_lane(); }
+                    node_step(S, o, inv, t_min, t_max, node, leaf);
+                    stepping = leaf == 0u && node < RT_NODE_END_SUB;
+                }
+            } while ((uint32_t)__popcll(__ballot(stepping)) >= floor_lanes);
+            if (ws) { W.node = node; W.leaf = leaf; }
         }
     }
     if (COUNT) {
