@@ -236,6 +236,8 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
         // sync[0] = slot dispenser, sync[1] = next unstarted path, sync[2..] = active slots after each bounce
         uint32_t init_sync[2] = {0u, pool.n_slots < P.n_paths ? pool.n_slots : P.n_paths};
         HIP_TRY(hipMemcpyAsync(s->d_sync, init_sync, sizeof(init_sync), hipMemcpyHostToDevice, stream));
+        // with max_depth == 0 trace() returns black without looking at the scene: no path ever writes its radiance
+        if (P.max_depth == 0) HIP_TRY(hipMemsetAsync(s->d_radiance, 0, (size_t)P.n_paths * sizeof(float4), stream));
         rt_launch_init(&cam, s->d_pattern, &P, &pool, stream);
         HIP_TRY(hipGetLastError());
         // Bounce loop: the device reports after every bounce how many slots still hold a ray; the host enqueues

@@ -1,0 +1,215 @@
+"""Parity of the HIP path (through the C ABI, raytracing_amd.DeviceScene) with the CPU oracle and the committed golden
+vectors.  Bar (integer / index work and, because both sides evaluate the same IEEE operations in the same order, floats too):
+bit-exact primitive ids, hit distances, normals, per-path radiance and images."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import raytracing_amd as rt
+from raytracing_amd import _ffi as ffi
+from conftest import SCENES
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+F = np.float32
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=F).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def scenes(scene_cache):
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            world, kw = scene_cache(name, 8)
+            cache[name] = (world, kw, rt.DeviceScene(world), O.OracleScene(world))
+        return cache[name]
+    yield get
+    for _, _, dev, _ in cache.values():
+        dev.close()
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_golden_vectors(name, scenes):
+    """The committed vectors (closest hits of 1024 fixed rays, 256 path radiances, a 24x16 image) reproduced bit for bit."""
+    from make_golden import golden_inputs, W, H
+    g = np.load(os.path.join(HERE, "golden", f"golden_{name}.npz"))
+    world, cam, pat, bg, rays, ids = golden_inputs(name)
+    dev = rt.DeviceScene(world)
+    try:
+        hits = dev.trace_rays(g["rays"])
+        np.testing.assert_array_equal(hits["prim_id"], g["hit_prim_id"])          # check (1): ids bit-exact
+        np.testing.assert_array_equal(hits["sub_id"], g["hit_sub_id"])
+        np.testing.assert_array_equal(bits(hits["t"]), bits(g["hit_t"]))           # check (2): exceeds the 1e-5 bar
+        np.testing.assert_array_equal(bits(hits["normal"]), bits(g["hit_normal"]))
+        np.testing.assert_array_equal(bits(hits["uv"]), bits(g["hit_uv"]))
+        np.testing.assert_array_equal(hits["front"], g["hit_front"])
+        np.testing.assert_array_equal(bits(dev.trace_paths(cam, pat, bg, W, H, g["ids"])), bits(g["radiance"]))
+        img, _ = dev.render(cam, pat, bg, W, H)
+        np.testing.assert_array_equal(bits(img), bits(g["image"]))
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_primary_and_secondary_rays_vs_oracle(name, scenes):
+    """Fixed ray sets: a dense primary grid, and incoherent rays started inside the scene in random directions."""
+    world, kw, dev, ref = scenes(name)
+    cam = kw["camera"]
+    rays = O.primary_rays(cam, kw["width"], kw["height"], 160, 120, time=0.25)
+    rng = np.random.default_rng(11)
+    a = ref.trace_rays(rays)
+    pts = rays[:, :3] + rays[:, 3:6] * np.where(np.isfinite(a["t"]), a["t"] * 0.9, 1.0)[:, None]
+    d = rng.normal(size=(len(rays), 3)).astype(F)
+    sec = np.concatenate([pts, d, rng.uniform(0, 1, (len(rays), 1))], axis=1).astype(F)
+    for batch in (rays, sec):
+        a = ref.trace_rays(batch)
+        b = dev.trace_rays(batch)
+        np.testing.assert_array_equal(a["prim_id"], b["prim_id"])
+        np.testing.assert_array_equal(a["sub_id"], b["sub_id"])
+        np.testing.assert_array_equal(bits(a["t"]), bits(b["t"]))
+        np.testing.assert_array_equal(bits(a["normal"]), bits(b["normal"]))
+        np.testing.assert_array_equal(bits(a["uv"]), bits(b["uv"]))
+        np.testing.assert_array_equal(a["front"], b["front"])
+        assert (a["prim_id"] >= 0).sum() > 1000
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_paths_and_image_vs_oracle(name, scenes):
+    world, kw, dev, ref = scenes(name)
+    cam, pat, bg = kw["camera"], kw["pattern"], kw["background"]
+    W, H = 72, 40                       # not multiples of 8 or 64: ragged tiles
+    ids = np.array([(i, j, n) for j in range(0, H, 3) for i in range(0, W, 2) for n in range(0, 8, 3)], np.int32)
+    np.testing.assert_array_equal(bits(ref.trace_paths(cam, pat, bg, W, H, ids)), bits(dev.trace_paths(cam, pat, bg, W, H, ids)))
+    img, st = dev.render(cam, pat, bg, W, H)
+    want = ref.render(cam, pat, bg, W, H)
+    # check (3): the image is not merely within an RMSE, it is identical (same paths, same summation order)
+    np.testing.assert_array_equal(bits(img), bits(want))
+    assert st.paths == W * H * 8
+
+
+def test_edge_cases(scenes, monkeypatch):
+    world, kw, dev, ref = scenes("cornell_smoke_box")
+    cam, bg = kw["camera"], kw["background"]
+    pat = rt.Halton_sequence32(5)
+    # smallest legal image, one pattern column, MSAA table as pattern, depth limits
+    for W, H, p, depth in ((2, 2, pat[:, :1], 50), (9, 3, rt.MSAA_S16.astype(F), 50), (16, 16, pat, 1), (16, 16, pat, 2), (8, 8, pat, 0)):
+        img, _ = dev.render(cam, p, bg, W, H, max_depth=depth)
+        np.testing.assert_array_equal(bits(img), bits(ref.render(cam, p, bg, W, H, max_depth=depth)))
+    # few slots (every slot is reused many times) and a tiny radiance budget (several column batches): same image
+    want = ref.render(cam, pat, bg, 40, 24)
+    monkeypatch.setenv("RT_AMD_SLOTS", "1024")
+    monkeypatch.setenv("RT_AMD_RADIANCE_MIB", "1")
+    img, _ = dev.render(cam, pat, bg, 40, 24)
+    np.testing.assert_array_equal(bits(img), bits(want))
+    monkeypatch.delenv("RT_AMD_SLOTS")
+    monkeypatch.delenv("RT_AMD_RADIANCE_MIB")
+    monkeypatch.setenv("RT_AMD_NO_REGROUP", "1")     # material regrouping only changes which lane shades which slot
+    img, _ = dev.render(cam, pat, bg, 40, 24)
+    np.testing.assert_array_equal(bits(img), bits(want))
+    monkeypatch.delenv("RT_AMD_NO_REGROUP")
+    # a different seed gives a different (but again reproducible) image
+    a, _ = dev.render(cam, pat, bg, 40, 24, seed=7)
+    b, _ = dev.render(cam, pat, bg, 40, 24, seed=7)
+    np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(a, img)
+    np.testing.assert_array_equal(bits(a), bits(ref.render(cam, pat, bg, 40, 24, seed=7)))
+    # counters variant renders the same image and reports plausible counts
+    c, st = dev.render(cam, pat, bg, 40, 24, flags=ffi.RT_FLAG_COUNTERS)
+    np.testing.assert_array_equal(c, img)
+    assert st.rays >= st.paths > 0 and st.node_visits > st.rays
+
+
+def test_errors_on_device(scenes):
+    world, kw, dev, ref = scenes("cornell_box")
+    L = ffi.lib()
+    out = np.zeros(12, F)
+    pat = np.zeros(2, F)
+    bg = np.zeros(3, F)
+    cam = rt.render.__globals__["camera_record"](kw["camera"])
+    assert L.rt_render(dev.handle, C.byref(cam), ffi.fptr(pat), 1, ffi.fptr(bg), 1, 2, 50, 0, 0, ffi.fptr(out), None) == -1
+    assert b"at least 2" in L.rt_last_error()
+    assert L.rt_render(dev.handle, C.byref(cam), ffi.fptr(pat), 0, ffi.fptr(bg), 2, 2, 50, 0, 0, ffi.fptr(out), None) == -1
+    assert L.rt_render(dev.handle, C.byref(cam), ffi.fptr(pat), 1, ffi.fptr(bg), 2, 2, 99, 0, 0, ffi.fptr(out), None) == -1
+    assert dev.trace_rays(np.zeros((0, 7), F))["t"].shape == (0,)
+
+
+def test_sample_sharding_sums_to_the_full_frame(scenes):
+    """rt_render_accumulate over disjoint column shards + host-side sum + rt_finalize == one full render up to FP32
+    summation order (what the multi-GPU all-reduce does)."""
+    import torch
+    world, kw, dev, ref = scenes("cu_cover2")
+    cam, bg = kw["camera"], kw["background"]
+    pat = rt.Halton_sequence32(12)
+    W, H = 64, 48
+    full, _ = dev.render(cam, pat, bg, W, H)
+    total = torch.zeros(3 * W * H, dtype=torch.float32, device="cuda")
+    for g in (3,):
+        total.zero_()
+        for r in range(g):
+            acc = torch.zeros(3 * W * H, dtype=torch.float32, device="cuda")
+            dev.accumulate(cam, pat, bg, W, H, acc.data_ptr(), sample_first=r, sample_stride=g,
+                           stream=torch.cuda.current_stream().cuda_stream)
+            total += acc
+        out = torch.zeros_like(total)
+        dev.finalize(total.data_ptr(), 12, W, H, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        img = out.cpu().numpy().reshape(W, H, 3).transpose(1, 0, 2)
+        np.testing.assert_allclose(img, full, rtol=2e-6, atol=1e-7)
+
+
+def test_full_size_cu_cover2_against_oracle_and_properties(scenes):
+    """BASELINE configuration at full resolution (800x800): a few pattern columns against the oracle bit for bit, and
+    size-independent properties at more columns: run-to-run determinism and column-additivity."""
+    world, kw, dev, ref = scenes("cu_cover2")
+    cam, bg = kw["camera"], kw["background"]
+    W, H = kw["width"], kw["height"]
+    pat = rt.Halton_sequence32(2)
+    img, _ = dev.render(cam, pat, bg, W, H)
+    np.testing.assert_array_equal(bits(img), bits(ref.render(cam, pat, bg, W, H)))
+    pat = rt.Halton_sequence32(64)
+    a, st = dev.render(cam, pat, bg, W, H)
+    b, _ = dev.render(cam, pat, bg, W, H)
+    np.testing.assert_array_equal(a, b)
+    assert np.isfinite(a).all() and st.paths == W * H * 64
+    # gross appearance of the reference's own cu_cover2 picture (its scene is unseeded, so only the level is comparable):
+    # linear-space mean RGB (0.106, 0.164, 0.143) in outputs/cu_cover2_1000_samples.png
+    lin = np.clip(a, 0, 1) ** 2
+    assert np.all(np.abs(lin.mean(axis=(0, 1)) - np.array([0.1063, 0.1642, 0.1427])) < 0.03)
+
+
+@pytest.mark.parametrize("name,key,spp,tol", [("cornell_box", "cornell_box_10000", 2000, 0.012),
+                                              ("cornell_smoke_box", "cornell_smoke_box_10000", 1000, 0.012)])
+def test_converged_image_against_reference_gallery(name, key, spp, tol, scene_cache):
+    """The two deterministic scenes at full resolution against statistics of the reference's own rendered PNGs
+    (tests/golden/gallery_stats.json): per-channel RMSE of block means in gamma space, mean level, black frame.
+    Stated RMSE bound: 0.012 on 16x16 (24x24) block means, about twice the 1000-vs-10000 spp noise floor (0.0053)
+    measured between the reference's own two Cornell images."""
+    stats = json.load(open(os.path.join(HERE, "golden", "gallery_stats.json")))[key]
+    world, kw = rt.get_scene(name, spp=spp)
+    dev = rt.DeviceScene(world)
+    try:
+        img, st = dev.render(kw["camera"], kw["pattern"], kw["background"], kw["width"], kw["height"])
+    finally:
+        dev.close()
+    assert img.shape == (stats["height"], stats["width"], 3)
+    g = np.clip(img, 0, 1).astype(np.float64)       # the PNG is clamp01 of the same sqrt-gamma values
+    g = np.round(g * 255) / 255
+    blk = stats["block"]
+    gh, gw = g.shape[0] // blk, g.shape[1] // blk
+    mine = g[:gh * blk, :gw * blk].reshape(gh, blk, gw, blk, 3).mean(axis=(1, 3))
+    want = np.array(stats["block_means_gamma"])
+    rmse = np.sqrt(((mine - want) ** 2).mean(axis=(0, 1)))
+    assert (rmse < tol).all(), rmse
+    np.testing.assert_allclose((g ** 2).mean(axis=(0, 1)), stats["linear_mean"], atol=0.004)
+    row = g[g.shape[0] // 2].sum(axis=1)
+    assert abs(int(np.argmax(row > 0.02)) - stats["black_frame_px"]) <= 1
