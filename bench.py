@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scene", default="cu_cover2")
     ap.add_argument("--spp", type=int, default=1000)
-    ap.add_argument("--cpu-spp", type=int, default=6, help="pattern columns of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=64, help="pattern columns of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
@@ -140,13 +140,25 @@ def main():
             cpu = {"value": st.paths / st.seconds / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
                    "sample": "%s %dx%d, %d of %d pattern columns (%.1f s)" % (args.scene, W, H, args.cpu_spp, n, st.seconds)}
             flops_pp, bytes_pp, events = algorithmic_work(st)
-            paths_per_launch = W * H * len(range(0, n, 1))
-            tflops = flops_pp * paths_per_launch / (kernel_ms * 1e-3) / 1e12
-            roofline = {"bound": "valu_fp32", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            # Dominant kernel = rt_extend_kernel (BVH traversal + intersection).  Its launches of one extra frame are
+            # bracketed with HIP events on the launch stream (RT_FLAG_TIMING); algorithmic work per launch = the
+            # traversal/intersection share of the per-path work x the paths of a frame / launches.
+            from raytracing_amd import _ffi
+            scene.accumulate(cam, pattern, bg, W, H, accum.data_ptr(), flags=_ffi.RT_FLAG_TIMING, stream=stream)
+            tst = scene.counters()
+            trav = sum(events[k] * COST[k][0] for k in ("node", "sphere", "moving_sphere", "rect", "box", "transform", "medium", "triangle"))
+            trav_b = sum(events[k] * COST[k][1] for k in ("node", "sphere", "moving_sphere", "rect", "box", "transform", "medium", "triangle"))
+            launches = max(1, tst.extend_launches)
+            avg_s = tst.extend_seconds / launches
+            paths_per_launch = W * H * n / launches
+            tflops = trav * paths_per_launch / avg_s / 1e12
+            roofline = {"bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                         "frac": tflops / PEAK_FP32_TFLOPS, "traffic": None,
-                        "kernel": "rt_render_kernel", "kernel_ms": kernel_ms,
-                        "flops_per_path": flops_pp, "l2_bytes_per_path": bytes_pp,
-                        "node_fetch_GBps": bytes_pp * paths_per_launch / (kernel_ms * 1e-3) / 1e9,
+                        "kernel": "rt_extend_kernel", "launches_per_frame": int(launches),
+                        "avg_launch_ms": avg_s * 1e3, "extend_ms_per_frame": tst.extend_seconds * 1e3,
+                        "shade_ms_per_frame": tst.shade_seconds * 1e3,
+                        "flops_per_path": trav, "bytes_per_path": trav_b, "flops_per_path_incl_shading": flops_pp,
+                        "node_fetch_GBps": trav_b * paths_per_launch / avg_s / 1e9,
                         "events_per_path": {k: round(v, 3) for k, v in events.items()}}
             pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(pmc):

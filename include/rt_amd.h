@@ -151,9 +151,14 @@ typedef struct rtStats {
     /* wave-level loop iterations of the three loops (64 lanes each): lane utilisation of a loop =
      * per-lane events / (64 * wave steps).  0 unless RT_FLAG_COUNTERS */
     uint64_t node_wave_steps, prim_wave_steps, bounce_wave_steps;
+    /* device time (HIP events on the launch stream) and launch counts of the two kernels of a bounce;
+     * 0 unless RT_FLAG_TIMING */
+    double extend_seconds, shade_seconds;
+    uint64_t extend_launches, shade_launches;
 } rtStats;
 
-#define RT_FLAG_COUNTERS 1u /* run the counting variant of the kernel (slower) */
+#define RT_FLAG_COUNTERS 1u /* run the counting variant of the extend kernel (slower) */
+#define RT_FLAG_TIMING 2u   /* bracket every extend / shade launch with HIP events (adds a little launch overhead) */
 
 typedef struct rtScene rtScene;
 

@@ -15,6 +15,7 @@ RT_SPHERE, RT_MOVING_SPHERE, RT_XY_RECT, RT_XZ_RECT, RT_YZ_RECT = 1, 2, 3, 4, 5
 RT_BOX, RT_TRANSFORM, RT_CONSTANT_MEDIUM, RT_BVH, RT_MESH = 6, 7, 8, 9, 10
 RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_IMAGE, RT_TEX_NOISE_MARBLE, RT_TEX_NOISE_SCALAR = 0, 1, 2, 3, 4
 RT_FLAG_COUNTERS = 1
+RT_FLAG_TIMING = 2
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -82,7 +83,9 @@ class rtCamera(C.Structure):
 class rtStats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("paths", C.c_uint64), ("rays", C.c_uint64),
                 ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64), ("node_wave_steps", C.c_uint64),
-                ("prim_wave_steps", C.c_uint64), ("bounce_wave_steps", C.c_uint64)]
+                ("prim_wave_steps", C.c_uint64), ("bounce_wave_steps", C.c_uint64),
+                ("extend_seconds", C.c_double), ("shade_seconds", C.c_double),
+                ("extend_launches", C.c_uint64), ("shade_launches", C.c_uint64)]
 
 
 # every symbol include/rt_amd.h declares: name -> (restype, argtypes)

@@ -49,6 +49,9 @@ struct rtScene {
     unsigned long long* d_counters = nullptr;
     hipStream_t last_stream = nullptr;
     uint64_t last_paths = 0;
+    hipEvent_t* events = nullptr;                      // 3 per bounce of a batch, RT_FLAG_TIMING only
+    double last_extend_s = 0.0, last_shade_s = 0.0;
+    uint64_t last_extend_launches = 0, last_shade_launches = 0;
 };
 
 #define SYNC_WORDS 4096u   // word 0: slot dispenser; words 1..: ring of per-bounce active counts
@@ -183,6 +186,10 @@ int rt_scene_destroy(rtScene* s) {
     if (s->d_pool) (void)hipFree(s->d_pool);
     if (s->d_sync) (void)hipFree(s->d_sync);
     if (s->h_sync) (void)hipHostFree(s->h_sync);
+    if (s->events) {
+        for (uint32_t i = 0; i < 3u * BOUNCE_BATCH; ++i) (void)hipEventDestroy(s->events[i]);
+        delete[] s->events;
+    }
     if (s->d_accum) (void)hipFree(s->d_accum);
     if (s->d_counters) (void)hipFree(s->d_counters);
     delete s;
@@ -226,6 +233,14 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
     HIP_TRY(hipMemcpyAsync(s->d_pattern, pattern, (size_t)2 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, stream));
     bool count = (flags & RT_FLAG_COUNTERS) != 0;
     if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), stream));
+    bool timing = (flags & RT_FLAG_TIMING) != 0;
+    if (timing && !s->events) {
+        s->events = new (std::nothrow) hipEvent_t[3u * BOUNCE_BATCH];
+        if (!s->events) return rt_fail(RT_ENOMEM, "out of host memory");
+        for (uint32_t i = 0; i < 3u * BOUNCE_BATCH; ++i) HIP_TRY(hipEventCreate(&s->events[i]));
+    }
+    s->last_extend_s = s->last_shade_s = 0.0;
+    s->last_extend_launches = s->last_shade_launches = 0;
     RtCameraDev cam;
     camera_to_dev(camera, &cam);
     uint32_t extend_blocks = (uint32_t)(s->n_cus > 0 ? s->n_cus : 256) * (uint32_t)env_int("RT_AMD_EXTEND_BLOCKS_PER_CU", 6);
@@ -246,10 +261,21 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
             HIP_TRY(hipMemsetAsync(s->d_sync + 2, 0, BOUNCE_BATCH * sizeof(uint32_t), stream));
             for (uint32_t b = 0; b < BOUNCE_BATCH; ++b)
                 rt_launch_bounce(&s->dev, &cam, s->d_pattern, &P, &pool, extend_blocks, s->d_radiance, s->d_sync,
-                                 s->d_sync + 2u + b, s->d_counters, count, stream);
+                                 s->d_sync + 2u + b, s->d_counters, count, timing ? s->events + 3u * b : nullptr, stream);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(s->h_sync, s->d_sync + 1u + BOUNCE_BATCH, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
+            if (timing) {
+                for (uint32_t b = 0; b < BOUNCE_BATCH; ++b) {
+                    float ms_e = 0.0f, ms_s = 0.0f;
+                    HIP_TRY(hipEventElapsedTime(&ms_e, s->events[3u * b], s->events[3u * b + 1u]));
+                    HIP_TRY(hipEventElapsedTime(&ms_s, s->events[3u * b + 1u], s->events[3u * b + 2u]));
+                    s->last_extend_s += (double)ms_e * 1e-3;
+                    s->last_shade_s += (double)ms_s * 1e-3;
+                }
+                s->last_extend_launches += BOUNCE_BATCH;
+                s->last_shade_launches += BOUNCE_BATCH;
+            }
             if (s->h_sync[0] == 0u) break;
             if (bounce > ((uint64_t)P.n_paths / pool.n_slots + 2ull) * 64ull + 4096ull)
                 return rt_fail(RT_EHIP, "rt_render_accumulate: bounce loop did not terminate");
@@ -286,6 +312,10 @@ int rt_get_counters(rtScene* s, rtStats* stats) {
     stats->node_wave_steps = c[3];
     stats->prim_wave_steps = c[4];
     stats->bounce_wave_steps = c[5];
+    stats->extend_seconds = s->last_extend_s;
+    stats->shade_seconds = s->last_shade_s;
+    stats->extend_launches = s->last_extend_launches;
+    stats->shade_launches = s->last_shade_launches;
     return RT_OK;
 }
 
@@ -311,7 +341,7 @@ int rt_render(rtScene* s, const rtCamera* camera, const float* pattern, int n, c
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (stats) {
-        if (flags & RT_FLAG_COUNTERS) {
+        if (flags & (RT_FLAG_COUNTERS | RT_FLAG_TIMING)) {
             st = rt_get_counters(s, stats);
             if (st != RT_OK) return st;
         } else {

@@ -40,7 +40,7 @@ void rt_launch_init(const RtCameraDev* cam, const float* d_pattern, const RtRend
 // hold a ray after the bounce.
 void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, const float* d_pattern, const RtRenderParams* P,
                       const PathPool* pool, uint32_t extend_blocks, float4* d_radiance, uint32_t* d_sync, uint32_t* d_active,
-                      unsigned long long* d_counters, bool count, hipStream_t stream);
+                      unsigned long long* d_counters, bool count, hipEvent_t* timing, hipStream_t stream);
 void rt_launch_sum(const RtRenderParams* P, const float4* d_radiance, float* d_accum, int first_batch, hipStream_t stream);
 void rt_launch_finalize(const float* d_accum, float inv_n, size_t image_floats, float* d_out, hipStream_t stream);
 void rt_launch_trace_rays(const DevScene* S, const float* d_rays, int n, float t_min, float t_max, uint32_t seed32,

@@ -1200,12 +1200,17 @@ extern "C" void rt_launch_init(const RtCameraDev* cam, const float* d_pattern, c
 }
 extern "C" void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, const float* d_pattern, const RtRenderParams* P,
                                  const PathPool* pool, uint32_t extend_blocks, float4* d_radiance, uint32_t* d_sync,
-                                 uint32_t* d_active, unsigned long long* d_counters, bool count, hipStream_t stream) {
+                                 uint32_t* d_active, unsigned long long* d_counters, bool count, hipEvent_t* timing,
+                                 hipStream_t stream) {
+    // timing (optional): three events, before extend / between / after shade
     uint32_t shade_blocks = (pool->n_slots + SHADE_BLOCK - 1u) / SHADE_BLOCK;
+    if (timing) (void)hipEventRecord(timing[0], stream);
     if (count) hipLaunchKernelGGL(rt_extend_kernel<true>, dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
     else hipLaunchKernelGGL(rt_extend_kernel<false>, dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    if (timing) (void)hipEventRecord(timing[1], stream);
     hipLaunchKernelGGL(rt_shade_kernel, dim3(shade_blocks), dim3(SHADE_BLOCK), 0, stream, *S, *cam, d_pattern, *P, *pool, d_radiance,
                        d_sync, d_active);
+    if (timing) (void)hipEventRecord(timing[2], stream);
 }
 extern "C" void rt_launch_sum(const RtRenderParams* P, const float4* d_radiance, float* d_accum, int first_batch, hipStream_t stream) {
     hipLaunchKernelGGL(rt_sum_kernel, dim3((P->n_pixels + 255u) / 256u), dim3(256), 0, stream, *P, d_radiance, d_accum, first_batch);
