@@ -1,0 +1,37 @@
+// accel_build.h -- the device-side acceleration structure: one binary BVH per region (surfaces, media, every nested
+// tree), built with the surface-area heuristic over the primitives' bounding boxes and laid out once per ray-direction
+// octant so that the stackless walk of rt_kernels.hip meets the near child of every node first.
+#ifndef ACCEL_BUILD_H
+#define ACCEL_BUILD_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "rt_device.h"
+
+struct AccelItem {
+    float b[6];    // min.xyz, max.xyz
+    uint32_t leaf; // leaf word: (primitive index + 1) | flags
+};
+
+struct AccelNode {
+    float b[6];
+    int32_t child[2]; // child[0] holds the lower centroids along `axis`; -1 in leaves
+    int32_t axis;
+    uint32_t leaf;    // 0 in interior nodes
+    uint32_t size;    // nodes in the subtree, this one included
+};
+
+struct AccelTree {
+    std::vector<AccelNode> nodes; // root = 0; empty for no items
+};
+
+void accel_build(std::vector<AccelItem>& items, AccelTree& tree);
+
+// Appends the tree to `out` (2 x float4 per node: {min, bits(skip)}, {max, bits(leaf)}) in depth-first order; at every
+// interior node the child on the near side for rays of `octant` (bit a set: direction component a is negative) comes
+// first.  Skip links are indices into `out` counted in nodes; the links that leave the tree point one past its end.
+void accel_emit(const AccelTree& tree, int octant, std::vector<float4>& out);
+
+#endif

@@ -103,7 +103,8 @@ int fill_params(const float background[3], int width, int height, int max_depth,
     P->seed32 = fold_seed(seed);
     P->background[0] = background[0]; P->background[1] = background[1]; P->background[2] = background[2];
     P->image_floats = (size_t)3 * (size_t)width * (size_t)height;
-    P->leaf_threshold = (uint32_t)env_int("RT_AMD_LEAF_THRESHOLD", 16);
+    P->leaf_threshold = (uint32_t)env_int("RT_AMD_LEAF_THRESHOLD", 40);
+    P->blocked_threshold = (uint32_t)env_int("RT_AMD_BLOCKED_THRESHOLD", 12);
     P->fetch_threshold = (uint32_t)env_int("RT_AMD_FETCH_THRESHOLD", 16);
     P->step_dropout = (uint32_t)env_int("RT_AMD_STEP_DROPOUT", 8);
     P->regroup = std::getenv("RT_AMD_NO_REGROUP") ? 0u : 1u;
@@ -169,10 +170,11 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
         else s->n_cus = prop.multiProcessorCount;
     }
     if (st != RT_OK) { rt_scene_destroy(s); return st; }
-    s->dev.n_nodes = (uint32_t)(H.nodes.size() / 2);
+    s->dev.n_nodes = H.nodes_per_layout;
     s->dev.n_prims = (uint32_t)(H.prims.size() / 3);
     s->dev.surface_root = H.surface_root;
     s->dev.medium_root = H.medium_root;
+    s->dev.nested = H.nested ? 1u : 0u;
     *out = s;
     return RT_OK;
 }

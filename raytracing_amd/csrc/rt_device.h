@@ -1,14 +1,17 @@
 // rt_device.h -- device-resident scene layout shared by the host flattener (rt_scene.cpp)
 // and the gfx950 kernels (rt_kernels.hip).
 //
-// Layout in HBM (everything is small enough to stay L2-resident):
+// Layout in HBM (scenes of the size the reference ships stay L2-resident):
 //   nodes   : 32 B per node = 2 x float4:  {min.xyz, bits(skip)}, {max.xyz, bits(leaf)}
 //             Nodes are stored in depth-first pre-order.  Traversal is stackless: a node whose box is
 //             hit continues at node+1 (its first child) and every other case continues at `skip`
-//             (the next node in pre-order that is not a descendant).  leaf = primitive index + 1,
-//             0 for interior nodes.  The per-type trees of the host are laid out one after another,
-//             so one walk covers the whole SceneManager: first all trees of surfaces (ending in
-//             RT_NODE_END), then all trees of constant media (a second chain ending in RT_NODE_END).
+//             (the next node in pre-order that is not a descendant).  leaf = (primitive index + 1) |
+//             RT_LEAF_INSTANCE for nested trees, 0 for interior nodes.  One tree covers every surface of the
+//             SceneManager (its chain ends in RT_NODE_END), a second one the constant media, and the nested
+//             trees (Transform{BVHTree}) follow (their chains end in RT_NODE_END_SUB).  The whole array exists
+//             eight times, once per octant of ray directions, with the children of every node ordered near
+//             side first for that octant: layout o occupies nodes [o * n_nodes, (o + 1) * n_nodes) and its
+//             skip links stay inside it; roots are given relative to the layout.
 //   prims   : 48 B per primitive = 3 x uint4: {head, material, rank, g0}, {g1..g4}, {g5..g8}
 //             head = kind (bits 0-3) | medium flag (bit 4) | index field (bits 8-31):
 //             transform index + 1 (0 = none), or for triangles the attribute record index.
@@ -19,6 +22,7 @@
 
 #define RT_NODE_END 0xFFFFFFFFu     // traversal finished
 #define RT_NODE_END_SUB 0xFFFFFFFEu // end of a nested tree: restore the outer ray
+#define RT_LEAF_INSTANCE 0x80000000u // leaf word flag: the primitive is a nested tree (Transform{BVHTree})
 
 enum DevPrimKind {
     DP_SPHERE = 1,
@@ -51,9 +55,10 @@ struct DevScene {
     const int32_t* perlin_perm;  // 768 ints per perlin (x, y, z)
     const int32_t* prim_top;     // per primitive: position in the world vector (reported prim_id)
     const int32_t* prim_sub;     // per primitive: reported sub id base (triangle id / nested object index)
-    uint32_t n_nodes, n_prims;
-    uint32_t surface_root; // first node of the surface trees, RT_NODE_END if there are none
-    uint32_t medium_root;  // first node of the constant-medium trees, RT_NODE_END if there are none
+    uint32_t n_nodes, n_prims; // n_nodes: nodes per octant layout
+    uint32_t surface_root; // root of the surface tree (layout-relative), RT_NODE_END if there are no surfaces
+    uint32_t nested;       // 1 if the scene holds nested trees (Transform{BVHTree})
+    uint32_t medium_root;  // root of the constant-medium tree (layout-relative), RT_NODE_END if there are no media
 };
 
 #endif

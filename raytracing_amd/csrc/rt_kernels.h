@@ -25,7 +25,8 @@ struct RtRenderParams {
     uint32_t n_paths;                // (k_end - k_begin) * n_pixels
     uint32_t seed32;
     float background[3];
-    uint32_t leaf_threshold;         // wave vote: test pending leaves once this many lanes hold one
+    uint32_t leaf_threshold;         // wave vote: test queued leaves once this many lanes hold one
+    uint32_t blocked_threshold;      // ... or once this many lanes cannot step before their leaves are tested
     uint32_t fetch_threshold;        // extend kernel: refill the wave once this many lanes are idle
     uint32_t step_dropout;           // extend kernel: leave the node-stepping loop after this many lanes dropped out
     uint32_t regroup;                // shade kernel: regroup the workgroup's slots by material type

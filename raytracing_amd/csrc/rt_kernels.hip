@@ -255,28 +255,57 @@ __device__ __forceinline__ float triangle_t(const float* g, f3 o, f3 d, float t_
     return t;
 }
 
-// distance to a simple shape (sphere, moving sphere, rectangle, box) in the ray's current frame
-__device__ __forceinline__ float shape_t(uint32_t kind, const float* g, f3 o, f3 d, float time, float t_min,
-                                         float t_max, uint32_t& side) {
-    switch (kind) {
-        case DP_SPHERE:
-            return sphere_t(mk3(g[0], g[1], g[2]), g[3], o, d, t_min, t_max);
-        case DP_MOVING_SPHERE: { // src/sphere.jl:24-26
-            f3 c0 = mk3(g[0], g[1], g[2]), c1 = mk3(g[4], g[5], g[6]);
-            f3 center = c0 + ((time - g[3]) / (g[7] - g[3])) * (c1 - c0);
-            return sphere_t(center, g[8], o, d, t_min, t_max);
-        }
-        case DP_XY_RECT:
-            return rect_t(o.z, d.z, o.x, d.x, o.y, d.y, g[0], g[1], g[2], g[3], g[4], t_min, t_max);
-        case DP_XZ_RECT:
-            return rect_t(o.y, d.y, o.x, d.x, o.z, d.z, g[0], g[1], g[2], g[3], g[4], t_min, t_max);
-        case DP_YZ_RECT:
-            return rect_t(o.x, d.x, o.y, d.y, o.z, d.z, g[0], g[1], g[2], g[3], g[4], t_min, t_max);
-        case DP_BOX:
-            return box_t(g, o, d, t_min, t_max, side);
-        default:
-            return INF;
+// Distance to a surface primitive.  One code path per class so that a wave holding a mix of primitives does not
+// run one copy of the arithmetic per kind: spheres and moving spheres share sphere_t, the three rectangle kinds and
+// the six sides of a box share rect_t (ray components and bounds are selected per lane).
+__device__ __forceinline__ float surface_t(const DevScene& S, uint32_t kind, uint32_t field, const float* g, f3 o, f3 d,
+                                           float time, float t_min, float t_max, uint32_t& side, uint32_t& xf) {
+    side = 0;
+    if (kind == DP_TRIANGLE) {
+        f3 nrm;
+        float u, v;
+        return triangle_t(g, o, d, t_min, t_max, nrm, u, v);
     }
+    f3 ro = o, rd = d;
+    if (field) { // Transform: src/transform.jl:104-105
+        const float* T = S.xforms + 24u * (field - 1u) + 12;
+        ro = apply_point(T, o);
+        rd = apply_vec(T, d);
+        xf = field;
+    }
+    if (kind <= DP_MOVING_SPHERE) {
+        f3 center = mk3(g[0], g[1], g[2]);
+        float radius = g[3];
+        if (kind == DP_MOVING_SPHERE) { // src/sphere.jl:24-26
+            f3 c1 = mk3(g[4], g[5], g[6]);
+            center = center + ((time - g[3]) / (g[7] - g[3])) * (c1 - center);
+            radius = g[8];
+        }
+        return sphere_t(center, radius, ro, rd, t_min, t_max);
+    }
+    // rectangles (src/aarect.jl:49-95) and boxes (src/box.jl:9-24,43-83: front, back, top, bottom, right, left; strict <)
+    const bool isbox = kind == DP_BOX;
+    const uint32_t axis = isbox ? 2u : (kind == DP_XY_RECT ? 2u : (kind == DP_XZ_RECT ? 1u : 0u)); // constant axis
+    float ok = axis == 2u ? ro.z : (axis == 1u ? ro.y : ro.x), dk = axis == 2u ? rd.z : (axis == 1u ? rd.y : rd.x);
+    float oa = axis == 0u ? ro.y : ro.x, da = axis == 0u ? rd.y : rd.x;
+    float ob = axis == 2u ? ro.y : ro.z, db = axis == 2u ? rd.y : rd.z;
+    float best = rect_t(ok, dk, oa, da, ob, db, g[0], isbox ? g[3] : g[1], isbox ? g[1] : g[2], isbox ? g[4] : g[3],
+                        isbox ? g[5] : g[4], t_min, t_max);
+    if (isbox) {
+        if (best < INF) t_max = best; else best = INF;
+        float t;
+        t = rect_t(ro.z, rd.z, ro.x, rd.x, ro.y, rd.y, g[0], g[3], g[1], g[4], g[2], t_min, t_max);
+        if (t < best) { best = t; side = 1; t_max = t; }
+        t = rect_t(ro.y, rd.y, ro.x, rd.x, ro.z, rd.z, g[0], g[3], g[2], g[5], g[4], t_min, t_max);
+        if (t < best) { best = t; side = 2; t_max = t; }
+        t = rect_t(ro.y, rd.y, ro.x, rd.x, ro.z, rd.z, g[0], g[3], g[2], g[5], g[1], t_min, t_max);
+        if (t < best) { best = t; side = 3; t_max = t; }
+        t = rect_t(ro.x, rd.x, ro.y, rd.y, ro.z, rd.z, g[1], g[4], g[2], g[5], g[3], t_min, t_max);
+        if (t < best) { best = t; side = 4; t_max = t; }
+        t = rect_t(ro.x, rd.x, ro.y, rd.y, ro.z, rd.z, g[1], g[4], g[2], g[5], g[0], t_min, t_max);
+        if (t < best) { best = t; side = 5; t_max = t; }
+    }
+    return best;
 }
 
 // ------------------------------------------------------------------ closest hit over the whole scene
@@ -300,48 +329,50 @@ __device__ __forceinline__ uint32_t first_active_lane() {
 // the closest hit wins; among exactly equal distances the reference keeps the earlier type group and, inside
 // a group, the leaf its right-child-first stack order reaches first -- encoded here as `rank`.
 //
-// Two regions are walked one after the other: first every tree of surfaces, then the trees of constant media,
-// so that the (expensive, stochastic) medium test runs once per ray with the closest surface already known.
+// Surfaces and constant media are walked one after the other: first the tree of surfaces (the Walker below, or the
+// state machine of rt_extend_kernel), then the tree of media (media_closest), so that the (expensive, stochastic)
+// medium test runs with the closest surface already known.
 //
-// The walk is written as a per-lane state machine with two blocks, walker_step (fetch one node, box test) and
-// walker_leaf (test the pending leaf primitive).  The kernels run these blocks under a wave-wide vote (see
-// rt_render_kernel): at every iteration the 64 lanes of the wave execute the one block that most lanes are
-// waiting for, instead of each lane dragging the whole wave through its own control flow.
+// The surface walk is a per-lane state machine with two blocks, walker_step (fetch one node, box test) and
+// walker_leaf (test the pending leaf primitive).  Kernels run these blocks under a wave-wide vote: at every
+// iteration the 64 lanes of the wave execute the one block that most lanes are waiting for, instead of each lane
+// dragging the whole wave through its own control flow.
 struct Walker {
     f3 o, d, inv;              // ray in the frame being traversed (inv = 1/d for the box test)
     float time, t_min, t_max;  // t_max shrinks to the closest hit found so far
     f3 so, sd;                 // outer ray while inside a nested tree (a BVHTree inside a Transform)
     uint32_t ret, inst_rank, inst_xf;
-    uint32_t node;             // next node to visit, RT_NODE_END / RT_NODE_END_SUB at the end of a region
-    uint32_t leaf;             // pending leaf: primitive index + 1, 0 = none
-    uint32_t in_media;         // 1 while walking the constant-medium trees
+    uint32_t node;             // next node to visit, RT_NODE_END / RT_NODE_END_SUB at the end of a tree
+    uint32_t leaf;             // pending leaf word: (primitive index + 1) | flags, 0 = none
     Closest best;
 };
 
+// first node of the layout that orders children near side first for direction d (one layout per octant)
+__device__ __forceinline__ uint32_t layout_base(const DevScene& S, f3 d) {
+    uint32_t octant = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    return octant * S.n_nodes;
+}
 __device__ __forceinline__ void walker_start(Walker& W, const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max) {
     W.o = o; W.d = d;
     W.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     W.time = time; W.t_min = t_min; W.t_max = t_max;
     W.so = o; W.sd = d;
     W.ret = RT_NODE_END; W.inst_rank = 0; W.inst_xf = 0;
-    W.node = S.surface_root;
+    W.node = S.surface_root == RT_NODE_END ? RT_NODE_END : S.surface_root + layout_base(S, d);
     W.leaf = 0;
-    W.in_media = 0;
     W.best.t = INF; W.best.prim = 0xFFFFFFFFu; W.best.sx = 0; W.best.rank = 0;
 }
-__device__ __forceinline__ bool walker_finished(const Walker& W) {
-    return W.leaf == 0u && W.node == RT_NODE_END && W.in_media != 0u;
-}
+__device__ __forceinline__ bool walker_finished(const Walker& W) { return W.leaf == 0u && W.node == RT_NODE_END; }
 __device__ __forceinline__ bool walker_wants_leaf(const Walker& W) { return W.leaf != 0u; }
-__device__ __forceinline__ bool walker_wants_step(const Walker& W) { return W.leaf == 0u && !walker_finished(W); }
+__device__ __forceinline__ bool walker_wants_step(const Walker& W) { return W.leaf == 0u && W.node != RT_NODE_END; }
 
-__device__ __forceinline__ void consider(Walker& W, float t, uint32_t prim, uint32_t sx, uint32_t rank) {
-    if (t < W.best.t || (t == W.best.t && t != INF && rank > W.best.rank)) {
-        W.best.t = t;
-        W.best.prim = prim;
-        W.best.sx = sx;
-        W.best.rank = rank;
-        W.t_max = t;
+__device__ __forceinline__ void consider(Closest& best, float& t_max, float t, uint32_t prim, uint32_t sx, uint32_t rank) {
+    if (t < best.t || (t == best.t && t != INF && rank > best.rank)) {
+        best.t = t;
+        best.prim = prim;
+        best.sx = sx;
+        best.rank = rank;
+        t_max = t;
     }
 }
 
@@ -423,21 +454,7 @@ __device__ __forceinline__ float medium_t(const DevScene& S, uint32_t head, cons
     return t1 + hit_distance / ray_length;
 }
 
-// Region bookkeeping for a lane that ran off the end of a tree (leaf == 0 and node >= RT_NODE_END_SUB).
-__device__ __forceinline__ void walker_transition(Walker& W, const DevScene& S) {
-    if (W.node == RT_NODE_END_SUB) { // end of a nested tree: back to the outer ray
-        W.o = W.so; W.d = W.sd;
-        W.inv = mk3(1.0f / W.d.x, 1.0f / W.d.y, 1.0f / W.d.z);
-        W.node = W.ret;
-        W.inst_rank = 0; W.inst_xf = 0;
-    }
-    if (W.node == RT_NODE_END && W.in_media == 0u) { // surfaces done: continue with the media
-        W.node = S.medium_root;
-        W.in_media = 1u;
-    }
-}
-
-// One node: fetch + box test.  Call only for lanes with leaf == 0 and node < RT_NODE_END_SUB.
+// One node: fetch + box test.  Call only for node < RT_NODE_END_SUB.
 __device__ __forceinline__ void node_step(const DevScene& S, const f3& o, const f3& inv, float t_min, float t_max,
                                           uint32_t& node, uint32_t& leaf) {
     float4 q0 = S.nodes[2u * node], q1 = S.nodes[2u * node + 1u];
@@ -457,34 +474,68 @@ __device__ __forceinline__ void node_step(const DevScene& S, const f3& o, const 
     leaf = hit ? lf : 0u;
 }
 
+// The constant media of the scene for a ray whose closest surface is already in `best` (best.t = INF: none).
+// Every lane walks the (small) medium tree on its own; callers run this with all lanes of a wave active.
+__device__ __forceinline__ void media_closest(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max,
+                                              const RngKey& key, Closest& best) {
+    if (S.medium_root == RT_NODE_END) return;
+    uint32_t node = S.medium_root + layout_base(S, d);
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    if (best.t != INF) t_max = best.t;
+    while (node != RT_NODE_END) {
+        uint32_t leaf;
+        node_step(S, o, inv, t_min, t_max, node, leaf);
+        if (leaf) {
+            uint32_t prim = (leaf & ~RT_LEAF_INSTANCE) - 1u;
+            uint4 head;
+            Geom G;
+            load_prim(S, prim, head, G);
+            float t = medium_t(S, head.x, G.g, o, d, time, t_min, t_max, key);
+            consider(best, t_max, t, prim, (head.x >> 8) << 3, head.z);
+        }
+    }
+}
+
+// back out of a nested tree (node == RT_NODE_END_SUB): restore the outer ray
+__device__ __forceinline__ void walker_return(Walker& W) {
+    W.o = W.so; W.d = W.sd;
+    W.inv = mk3(1.0f / W.d.x, 1.0f / W.d.y, 1.0f / W.d.z);
+    W.node = W.ret;
+    W.inst_rank = 0; W.inst_xf = 0;
+}
+
 template <bool COUNT>
 __device__ __forceinline__ void walker_step(Walker& W, const DevScene& S, Counters& cnt) {
-    walker_transition(W, S);
+    if (W.node == RT_NODE_END_SUB) walker_return(W);
     if (W.node < RT_NODE_END_SUB) {
         if (COUNT) cnt.nodes++;
         node_step(S, W.o, W.inv, W.t_min, W.t_max, W.node, W.leaf);
     }
 }
 
+// One surface leaf for the ray (o, d) of the frame being walked.  A nested tree is entered (returns true, with the
+// new frame in `W`-style arguments handled by the caller); any other primitive is tested against `best`.
+__device__ __forceinline__ void surface_leaf(const DevScene& S, uint32_t prim, const uint4& head, const Geom& G, f3 o, f3 d,
+                                             float time, float t_min, float& t_max, uint32_t inst_rank, uint32_t inst_xf,
+                                             Closest& best) {
+    uint32_t kind = head.x & 15u;
+    uint32_t side = 0, xf = inst_xf;
+    float t = surface_t(S, kind, kind == DP_TRIANGLE ? 0u : head.x >> 8, G.g, o, d, time, t_min, t_max, side, xf);
+    consider(best, t_max, t, prim, side | (xf << 3), head.z + inst_rank);
+}
+
 // The pending leaf primitive.  Call only for lanes with walker_wants_leaf().
 template <bool COUNT>
-__device__ __forceinline__ void walker_leaf(Walker& W, const DevScene& S, const RngKey& key, Counters& cnt) {
-    uint32_t prim = W.leaf - 1u;
+__device__ __forceinline__ void walker_leaf(Walker& W, const DevScene& S, Counters& cnt) {
+    uint32_t prim = (W.leaf & ~RT_LEAF_INSTANCE) - 1u;
     W.leaf = 0u;
     uint4 head;
     Geom G;
     load_prim(S, prim, head, G);
     if (COUNT) cnt.prims++;
-    uint32_t kind = head.x & 15u;
-    uint32_t field = head.x >> 8;
-    uint32_t rank = head.z + W.inst_rank;
-    if (W.in_media) {
-        float t = medium_t(S, head.x, G.g, W.o, W.d, W.time, W.t_min, W.t_max, key);
-        consider(W, t, prim, field << 3, rank);
-        return;
-    }
-    if (kind == DP_INSTANCE) {
+    if ((head.x & 15u) == DP_INSTANCE) {
         // Transform{BVHTree}: src/transform.jl:104-116 around src/BVH.jl:22-53
+        uint32_t field = head.x >> 8;
         W.so = W.o; W.sd = W.d;
         W.ret = W.node;
         W.inst_rank = head.z;
@@ -495,26 +546,10 @@ __device__ __forceinline__ void walker_leaf(Walker& W, const DevScene& S, const 
             W.o = no; W.d = nd;
             W.inv = mk3(1.0f / nd.x, 1.0f / nd.y, 1.0f / nd.z);
         }
-        W.node = __float_as_uint(G.g[0]);
+        W.node = __float_as_uint(G.g[0]) + layout_base(S, W.d);
         return;
     }
-    float t;
-    uint32_t side = 0, xf = W.inst_xf;
-    if (kind == DP_TRIANGLE) {
-        f3 nrm;
-        float u, v;
-        t = triangle_t(G.g, W.o, W.d, W.t_min, W.t_max, nrm, u, v);
-    } else {
-        f3 ro = W.o, rd = W.d;
-        if (field) { // Transform: src/transform.jl:104-105
-            const float* T = S.xforms + 24u * (field - 1u) + 12;
-            ro = apply_point(T, W.o);
-            rd = apply_vec(T, W.d);
-            xf = field;
-        }
-        t = shape_t(kind, G.g, ro, rd, W.time, W.t_min, W.t_max, side);
-    }
-    consider(W, t, prim, side | (xf << 3), rank);
+    surface_leaf(S, prim, head, G, W.o, W.d, W.time, W.t_min, W.t_max, W.inst_rank, W.inst_xf, W.best);
 }
 
 // Wave-wide vote: which block should the wave run now?  0 = step, 1 = leaf, 2 = shade, 3 = nothing left.
@@ -544,9 +579,10 @@ __device__ __forceinline__ void closest_hit(const DevScene& S, f3 o, f3 d, float
         int block = wave_vote(ws, wl, false, V);
         if (block == 3) break;
         if (block == 0) { if (ws) walker_step<COUNT>(W, S, cnt); }
-        else { if (wl) walker_leaf<COUNT>(W, S, key, cnt); }
+        else { if (wl) walker_leaf<COUNT>(W, S, cnt); }
     }
     best = W.best;
+    if (active) media_closest(S, o, d, time, t_min, t_max, key, best);
 }
 
 // ------------------------------------------------------------------ hit completion (only for the winner)
@@ -893,35 +929,53 @@ __global__ void __launch_bounds__(256) rt_init_kernel(RtCameraDev cam, const flo
     }
 }
 
-template <bool COUNT>
+// Closest surface of every slot's ray.  Persistent waves; each lane is a small state machine:
+//   * it steps through BVH nodes (hot loop) and collects the leaves it meets in a three-entry queue, so that it
+//     keeps stepping (with a t_max that is at most three leaves stale) instead of stopping at every leaf;
+//   * queued leaves are tested in the leaf block, which the wave runs when enough lanes hold leaves or too many
+//     lanes cannot step any more (queue full, tree finished with leaves pending, nested tree waiting to be entered);
+//   * a lane whose walk is over publishes its hit and fetches the next slot in the retire/fetch block.
+// Which block runs is a wave-wide vote.  Constant media are left to rt_shade_kernel.  NESTED: the scene holds nested
+// trees (Transform{BVHTree}); without them the state for the outer ray is not carried.
+#define LEAF_QUEUE 3u
+template <bool COUNT, bool NESTED>
 __global__ void __launch_bounds__(256) rt_extend_kernel(DevScene S, RtRenderParams P, PathPool pool, uint32_t* __restrict__ head,
                                                         unsigned long long* __restrict__ counters) {
     const uint32_t lane = threadIdx.x & 63u;
-    const bool media = S.medium_root != RT_NODE_END;
+    const float t_min = 0.001f;
     Counters cnt = {0, 0, 0, 0, 0, 0};
     uint32_t cur = 0, end = 0; // wave-uniform cursor into the chunk of slots this wave owns
     bool exhausted = false;
     bool busy = false;
     uint32_t slot = 0;
-    RngKey key = {0u, 0u, P.seed32, 0u};
-    Walker W;
-    walker_start(W, S, mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 1.0f), 0.0f, 0.001f, INF);
+    f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f), inv = mk3(0.0f, 0.0f, 1.0f);
+    float time = 0.0f, t_max = INF;
+    f3 so = o, sd = d; // outer ray while inside a nested tree
+    uint32_t ret = RT_NODE_END, inst_rank = 0, inst_xf = 0;
+    uint32_t node = RT_NODE_END;
+    uint32_t q0 = 0, q1 = 0, q2 = 0, nq = 0; // leaf queue: q0 newest; entry nq - 1 is the oldest
+    Closest best = {INF, 0xFFFFFFFFu, 0u, 0u};
     for (;;) {
-        // ---- lanes that ran off a tree: next region / back out of a nested tree (cheap, no vote needed)
-        if (busy && W.leaf == 0u && W.node >= RT_NODE_END_SUB && !walker_finished(W)) walker_transition(W, S);
+        // ---- end of a nested tree with nothing pending: back to the outer ray (cheap, no vote needed)
+        if (NESTED && busy && nq == 0u && node == RT_NODE_END_SUB) {
+            o = so; d = sd;
+            inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            node = ret;
+            inst_rank = 0; inst_xf = 0;
+        }
+        const bool fin = busy && nq == 0u && node == RT_NODE_END;
+        const bool wl = busy && nq != 0u;
+        const bool ws = busy && node < RT_NODE_END_SUB && nq < LEAF_QUEUE && !(NESTED && nq != 0u && (q0 & RT_LEAF_INSTANCE));
+        const uint32_t n_need = (uint32_t)__popcll(__ballot(!busy || fin));
+        const uint32_t nl = (uint32_t)__popcll(__ballot(wl));
+        const uint32_t ns = (uint32_t)__popcll(__ballot(ws));
 
         // ---- retire finished rays and fetch new ones once enough lanes are idle
-        bool fin = busy && walker_finished(W);
-        bool wl = busy && W.leaf != 0u;
-        bool ws = busy && W.leaf == 0u && W.node < RT_NODE_END_SUB;
-        uint32_t n_need = (uint32_t)__popcll(__ballot(!busy || fin));
-        uint32_t nl = (uint32_t)__popcll(__ballot(wl));
-        uint32_t ns = (uint32_t)__popcll(__ballot(ws));
         if ((n_need >= P.fetch_threshold && !exhausted) || (nl | ns) == 0u) {
             if (fin) { // publish the hit for the shade kernel
                 uint32_t type = HIT_MISS;
-                if (W.best.t != INF) type = S.materials[S.prims[3u * W.best.prim].y].x & 0xFFu;
-                QP(pool, 4, slot) = make_float4(W.best.t, __uint_as_float(W.best.prim), __uint_as_float(W.best.sx), __uint_as_float(type));
+                if (best.t != INF) type = S.materials[S.prims[3u * best.prim].y].x & 0xFFu;
+                QP(pool, 4, slot) = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(type));
                 if (COUNT) cnt.rays++;
                 busy = false;
             }
@@ -938,18 +992,20 @@ __global__ void __launch_bounds__(256) rt_extend_kernel(DevScene S, RtRenderPara
                     if (!busy) {
                         uint32_t sidx = cur + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                         if (sidx < end) {
-                            float4 q1 = QP(pool, 1, sidx);
-                            int depth = (int)__float_as_uint(q1.w);
+                            float4 p1 = QP(pool, 1, sidx);
+                            int depth = (int)__float_as_uint(p1.w);
                             if (depth > 0) {
-                                float4 q0 = QP(pool, 0, sidx);
+                                float4 p0 = QP(pool, 0, sidx);
                                 slot = sidx;
                                 busy = true;
-                                walker_start(W, S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, 0.001f, INF);
-                                if (media) { // the medium test draws a random number keyed by the path
-                                    int i, j, n;
-                                    path_ident(P, __float_as_uint(QP(pool, 2, sidx).w), i, j, n, key);
-                                    key.bounce = (uint32_t)(P.max_depth - depth);
-                                }
+                                o = mk3(p0.x, p0.y, p0.z); d = mk3(p1.x, p1.y, p1.z);
+                                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                                time = p0.w;
+                                t_max = INF;
+                                node = S.surface_root == RT_NODE_END ? RT_NODE_END : S.surface_root + layout_base(S, d);
+                                nq = 0u;
+                                inst_rank = 0; inst_xf = 0;
+                                best.t = INF; best.prim = 0xFFFFFFFFu; best.sx = 0u; best.rank = 0u;
                             }
                         }
                     }
@@ -960,27 +1016,52 @@ __global__ void __launch_bounds__(256) rt_extend_kernel(DevScene S, RtRenderPara
             continue;
         }
 
-        // ---- pending leaves, once enough lanes hold one (or nobody can step)
-        if (nl >= P.leaf_threshold || ns == 0u) {
-            if (wl) { if (COUNT) cnt.prim_waves += first_active_lane(); walker_leaf<COUNT>(W, S, key, cnt); }
+        // ---- queued leaves: once enough lanes hold one, or too many lanes cannot step before theirs are tested
+        const uint32_t n_blocked = (uint32_t)__popcll(__ballot(wl && !ws));
+        if (nl >= P.leaf_threshold || n_blocked >= P.blocked_threshold || ns == 0u) {
+            if (wl) {
+                if (COUNT) { cnt.prims++; cnt.prim_waves += first_active_lane(); }
+                uint32_t e = nq == 3u ? q2 : (nq == 2u ? q1 : q0);
+                nq -= 1u;
+                uint32_t prim = (e & ~RT_LEAF_INSTANCE) - 1u;
+                uint4 hd;
+                Geom G;
+                load_prim(S, prim, hd, G);
+                if (NESTED && (e & RT_LEAF_INSTANCE)) {
+                    // Transform{BVHTree}: src/transform.jl:104-116 around src/BVH.jl:22-53.  The flagged entry is
+                    // the last one a lane queues, so the queue is empty now.
+                    uint32_t field = hd.x >> 8;
+                    so = o; sd = d;
+                    ret = node;
+                    inst_rank = hd.z;
+                    inst_xf = field;
+                    if (field) {
+                        const float* T = S.xforms + 24u * (field - 1u) + 12;
+                        f3 no = apply_point(T, o), nd = apply_vec(T, d);
+                        o = no; d = nd;
+                        inv = mk3(1.0f / nd.x, 1.0f / nd.y, 1.0f / nd.z);
+                    }
+                    node = __float_as_uint(G.g[0]) + layout_base(S, d);
+                } else {
+                    surface_leaf(S, prim, hd, G, o, d, time, t_min, t_max, inst_rank, inst_xf, best);
+                }
+            }
             continue;
         }
 
         // ---- hot loop: step through nodes until `step_dropout` more lanes have left it
         {
-            uint32_t node = W.node, leaf = 0u;
-            const f3 o = W.o, inv = W.inv;
-            const float t_min = W.t_min, t_max = W.t_max;
             const uint32_t floor_lanes = ns > P.step_dropout ? ns - P.step_dropout : 1u;
             bool stepping = ws;
             do {
                 if (stepping) {
                     if (COUNT) { cnt.nodes++; cnt.node_waves += first_active_lane(); }
+                    uint32_t leaf;
                     node_step(S, o, inv, t_min, t_max, node, leaf);
-                    stepping = leaf == 0u && node < RT_NODE_END_SUB;
+                    if (leaf != 0u) { q2 = q1; q1 = q0; q0 = leaf; nq += 1u; }
+                    stepping = node < RT_NODE_END_SUB && nq < LEAF_QUEUE && !(NESTED && (leaf & RT_LEAF_INSTANCE));
                 }
             } while ((uint32_t)__popcll(__ballot(stepping)) >= floor_lanes);
-            if (ws) { W.node = node; W.leaf = leaf; }
         }
     }
     if (COUNT) {
@@ -1000,6 +1081,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
                                                                uint32_t* __restrict__ sync, uint32_t* __restrict__ active) {
     __shared__ uint32_t hist[8], cursor[8];
     __shared__ uint16_t order[SHADE_BLOCK];
+    __shared__ float4 hits[SHADE_BLOCK];  // per slot of the block: {t, prim, side|xform, type} after the media
+    __shared__ uint2 idents[SHADE_BLOCK]; // per slot of the block: {pixel, pattern column} of its path
     __shared__ uint32_t block_alive, block_need, block_base;
     const uint32_t t = threadIdx.x;
     const uint32_t base = blockIdx.x * SHADE_BLOCK;
@@ -1007,11 +1090,34 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
     if (t == 0u) { block_alive = 0u; block_need = 0u; }
     if (blockIdx.x == 0 && t == 0u) sync[0] = 0u; // re-arm the slot dispenser of the next rt_extend_kernel
     __syncthreads();
-    // material type of the slot this thread sits on; 7 = nothing to shade
+    // Phase 1, thread t on slot base + t: the constant media of the scene against the slot's ray (every lane of the
+    // wave has a ray, so the medium test runs converged), then the material type of the final hit; 7 = nothing to shade
     uint32_t my_key = 7u;
     if (base + t < pool.n_slots) {
-        int depth0 = (int)__float_as_uint(QP(pool, 1, base + t).w);
-        if (depth0 > 0) my_key = __float_as_uint(QP(pool, 4, base + t).w) & 7u;
+        float4 q1 = QP(pool, 1, base + t);
+        int depth0 = (int)__float_as_uint(q1.w);
+        if (depth0 > 0) {
+            float4 q4 = QP(pool, 4, base + t);
+            uint32_t p = __float_as_uint(QP(pool, 2, base + t).w);
+            int i, j, n;
+            RngKey key;
+            path_ident(P, p, i, j, n, key);
+            if (S.medium_root != RT_NODE_END) {
+                float4 q0 = QP(pool, 0, base + t);
+                key.bounce = (uint32_t)(P.max_depth - depth0);
+                Closest best;
+                best.t = q4.x; best.prim = __float_as_uint(q4.y); best.sx = __float_as_uint(q4.z); best.rank = 0u;
+                uint32_t surface = best.prim;
+                media_closest(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, 0.001f, INF, key, best);
+                if (best.prim != surface) {
+                    uint32_t type = S.materials[S.prims[3u * best.prim].y].x & 0xFFu;
+                    q4 = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(type));
+                }
+            }
+            hits[t] = q4;
+            idents[t] = make_uint2(key.pixel, key.sample);
+            my_key = __float_as_uint(q4.w) & 7u;
+        }
     }
     uint32_t mine = t;
     if (P.regroup) {
@@ -1026,20 +1132,22 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
         __syncthreads();
         uint32_t pos = atomicAdd(&cursor[my_key], 1u);
         order[pos] = (uint16_t)t;
-        __syncthreads();
-        mine = order[t];
     }
+    __syncthreads();
+    if (P.regroup) mine = order[t];
+    // Phase 2, thread t on slot base + mine: the body of trace()'s loop after the hit
     uint32_t slot = base + mine;
     bool valid = slot < pool.n_slots;
     float4 q1 = valid ? QP(pool, 1, slot) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     int depth = (int)__float_as_uint(q1.w);
     bool done = false, cont = false;
     if (valid && depth > 0) {
-        float4 q0 = QP(pool, 0, slot), q2 = QP(pool, 2, slot), q3 = QP(pool, 3, slot), q4 = QP(pool, 4, slot);
+        float4 q0 = QP(pool, 0, slot), q2 = QP(pool, 2, slot), q3 = QP(pool, 3, slot), q4 = hits[mine];
         uint32_t p = __float_as_uint(q2.w);
-        int i, j, n;
         RngKey key;
-        path_ident(P, p, i, j, n, key);
+        key.pixel = idents[mine].x;
+        key.sample = idents[mine].y;
+        key.seed32 = P.seed32;
         key.bounce = (uint32_t)(P.max_depth - depth);
         PathState ps;
         ps.acc = mk3(q2.x, q2.y, q2.z);
@@ -1179,12 +1287,15 @@ __global__ void __launch_bounds__(256) rt_trace_paths_kernel(DevScene S, RtCamer
         int block = wave_vote(ws, wl, wh, V);
         if (block == 3) break;
         if (block == 0) { if (ws) walker_step<false>(W, S, cnt); }
-        else if (block == 1) { if (wl) walker_leaf<false>(W, S, key, cnt); }
+        else if (block == 1) { if (wl) walker_leaf<false>(W, S, cnt); }
         else if (wh) {
             bool done = ps.depth <= 0;
             f3 no, nd;
             if (done) c = ps.color;
-            else done = shade(S, W.o, W.d, W.time, W.best, ps, bgc, key, c, no, nd);
+            else {
+                media_closest(S, W.o, W.d, W.time, 0.001f, INF, key, W.best);
+                done = shade(S, W.o, W.d, W.time, W.best, ps, bgc, key, c, no, nd);
+            }
             if (done) alive = false;
             else walker_start(W, S, no, nd, W.time, 0.001f, INF);
         }
@@ -1205,8 +1316,11 @@ extern "C" void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, cons
     // timing (optional): three events, before extend / between / after shade
     uint32_t shade_blocks = (pool->n_slots + SHADE_BLOCK - 1u) / SHADE_BLOCK;
     if (timing) (void)hipEventRecord(timing[0], stream);
-    if (count) hipLaunchKernelGGL(rt_extend_kernel<true>, dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
-    else hipLaunchKernelGGL(rt_extend_kernel<false>, dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    const bool nested = S->nested != 0u;
+    if (count && nested) hipLaunchKernelGGL((rt_extend_kernel<true, true>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    else if (count) hipLaunchKernelGGL((rt_extend_kernel<true, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    else if (nested) hipLaunchKernelGGL((rt_extend_kernel<false, true>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    else hipLaunchKernelGGL((rt_extend_kernel<false, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
     if (timing) (void)hipEventRecord(timing[1], stream);
     hipLaunchKernelGGL(rt_shade_kernel, dim3(shade_blocks), dim3(SHADE_BLOCK), 0, stream, *S, *cam, d_pattern, *P, *pool, d_radiance,
                        d_sync, d_active);

@@ -4,10 +4,13 @@
 // src/cuscene_manager.jl:16-19, src/mesh.jl:24-43, src/transform.jl:12-15, src/constant_medium.jl:12-16).
 #include "rt_scene.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <string>
 
+#include "accel_build.h"
 #include "rt_internal.h"
 
 namespace {
@@ -21,7 +24,7 @@ struct Builder {
     std::string err;
     int status = RT_OK;
 
-    std::vector<float4> sub_nodes;            // nested trees, relative indices
+    std::vector<float4> sub_nodes[8];         // nested trees (one copy per octant layout), relative indices
     std::vector<int64_t> group_root;          // per group: relative root index in sub_nodes, -1 = not emitted
     std::vector<uint32_t> instance_prims;     // prims whose g0 holds a relative sub-tree root
     std::map<std::vector<uint32_t>, uint32_t> xform_index; // identical matrices share one device record
@@ -188,26 +191,26 @@ struct Builder {
     }
 
     // ---------------------------------------------------------------- trees
-    static void push_node(std::vector<float4>& nodes, const float* b) {
-        nodes.push_back(make_float4(b[0], b[1], b[2], 0.0f));
-        nodes.push_back(make_float4(b[3], b[4], b[5], 0.0f));
-    }
-    static void set_skip(std::vector<float4>& nodes, size_t idx) { nodes[2 * idx].w = bitsf((uint32_t)(nodes.size() / 2)); }
-    static void set_leaf(std::vector<float4>& nodes, size_t idx, uint32_t prim) { nodes[2 * idx + 1].w = bitsf(prim + 1u); }
-
+    // The host trees (src/BVH.jl, src/mesh.jl) are walked once, depth first and left child first, to create the
+    // primitives with the tie-break ranks their tree positions imply and to pick up the reference's bounding box of
+    // every primitive.  The boxes then go to the device tree builder (accel_build.cpp).
     bool check_node(const rtBvh& T, int id, int depth) {
         if (id < 1 || id > T.n_nodes) return fail(RT_EINVAL, "BVH node id out of range");
         if (depth > 512) return fail(RT_EINVAL, "BVH deeper than 512 levels");
         if (++visited > (size_t)4 * (size_t)(T.n_nodes + 1) + 1024) return fail(RT_EINVAL, "BVH links form a cycle");
         return true;
     }
+    static void add_item(std::vector<AccelItem>& items, const float* box, uint32_t prim, uint32_t flags) {
+        AccelItem it;
+        std::memcpy(it.b, box, sizeof(it.b));
+        it.leaf = (prim + 1u) | flags;
+        items.push_back(it);
+    }
 
-    // generic tree (src/BVH.jl): pre-order, left child first
-    bool emit_generic(const rtBvh& T, int id, int depth, std::vector<float4>& nodes, uint32_t rank_base,
-                      const std::vector<uint32_t>* rank_offset, bool nested, int nested_top) {
+    // generic tree (src/BVH.jl)
+    bool collect_generic(const rtBvh& T, int id, int depth, std::vector<AccelItem>& items, uint32_t rank_base,
+                         const std::vector<uint32_t>* rank_offset, bool nested, int nested_top) {
         if (!check_node(T, id, depth)) return false;
-        size_t idx = nodes.size() / 2;
-        push_node(nodes, T.node_bounds + 6 * (size_t)(id - 1));
         if (T.node_leaf[id - 1]) {
             int l = T.node_left[id - 1], r = T.node_right[id - 1];
             if (l != r || l < 1 || l > T.n_objects) return fail(RT_EINVAL, "BVH leaf must reference exactly one object");
@@ -216,13 +219,20 @@ struct Builder {
             int top = nested ? nested_top : (valid_obj(oi) ? top_pos[(size_t)oi] : -1);
             uint32_t prim;
             if (!make_prim(oi, rank, top, nested ? oi : 0, nested, prim)) return false;
-            set_leaf(nodes, idx, prim);
-        } else {
-            if (!emit_generic(T, T.node_left[id - 1], depth + 1, nodes, rank_base, rank_offset, nested, nested_top)) return false;
-            if (!emit_generic(T, T.node_right[id - 1], depth + 1, nodes, rank_base, rank_offset, nested, nested_top)) return false;
+            bool instance = (H.prims[3 * (size_t)prim].x & 15u) == DP_INSTANCE;
+            add_item(items, T.node_bounds + 6 * (size_t)(id - 1), prim, instance ? RT_LEAF_INSTANCE : 0u);
+            return true;
         }
-        set_skip(nodes, idx);
-        return true;
+        return collect_generic(T, T.node_left[id - 1], depth + 1, items, rank_base, rank_offset, nested, nested_top) &&
+               collect_generic(T, T.node_right[id - 1], depth + 1, items, rank_base, rank_offset, nested, nested_top);
+    }
+
+    // Builds the device tree over `items` and appends its eight layouts to dst[0..7]; every layout gets the same
+    // number of nodes, so one layout-relative root index serves all of them.
+    void emit_tree(std::vector<AccelItem>& items, std::vector<float4>* dst) {
+        AccelTree tree;
+        accel_build(items, tree);
+        for (int o = 0; o < 8; ++o) accel_emit(tree, o, dst[o]);
     }
 
     bool emit_group(int gi, int top, int64_t& root) {
@@ -230,20 +240,27 @@ struct Builder {
         const rtBvh& T = D.groups[gi];
         if (T.kind != 0) return fail(RT_EUNSUPPORTED, "nested tree of meshes is not supported");
         if (T.n_objects <= 0 || T.n_nodes <= 0) return fail(RT_EINVAL, "empty nested tree");
-        size_t start = sub_nodes.size() / 2;
-        if (!emit_generic(T, 1, 0, sub_nodes, 0u, nullptr, true, top)) return false;
-        size_t end = sub_nodes.size() / 2;
-        for (size_t i = start; i < end; ++i)
-            if (fbits(sub_nodes[2 * i].w) == (uint32_t)end) sub_nodes[2 * i].w = bitsf(RT_NODE_END_SUB);
+        std::vector<AccelItem> items;
+        size_t saved = visited;
+        visited = 0;
+        bool ok = collect_generic(T, 1, 0, items, 0u, nullptr, true, top);
+        visited = saved;
+        if (!ok) return false;
+        size_t start = sub_nodes[0].size() / 2;
+        emit_tree(items, sub_nodes);
+        size_t end = sub_nodes[0].size() / 2;
+        for (int o = 0; o < 8; ++o)
+            for (size_t i = start; i < end; ++i)
+                if (fbits(sub_nodes[o][2 * i].w) == (uint32_t)end) sub_nodes[o][2 * i].w = bitsf(RT_NODE_END_SUB);
         group_root[(size_t)gi] = (int64_t)start;
         root = (int64_t)start;
         return true;
     }
 
-    // tree over meshes (src/mesh.jl:250-283): the mesh-level leaf becomes an interior node above its triangle tree
-    bool emit_tris(const rtBvh& T, const rtMesh& M, int top, int id, int depth, uint32_t rank_base) {
+    // tree over meshes (src/mesh.jl:250-283): every triangle becomes a primitive with its own bounding box
+    bool collect_tris(const rtBvh& T, const rtMesh& M, int top, int id, int depth, uint32_t rank_base,
+                      std::vector<AccelItem>& items) {
         if (!check_node(T, id, depth)) return false;
-        const float* box = T.node_bounds + 6 * (size_t)(id - 1);
         if (T.node_leaf[id - 1] == 1) {
             int l = T.node_left[id - 1], r = T.node_right[id - 1];
             if (l < 1 || r > M.n_triangles || l > r) return fail(RT_EINVAL, "triangle range out of bounds");
@@ -263,28 +280,36 @@ struct Builder {
                     a[9 + 2 * k] = v[6]; a[10 + 2 * k] = v[7];
                 }
                 H.tri_attr.insert(H.tri_attr.end(), a, a + 16);
-                size_t idx = H.nodes.size() / 2;
-                push_node(H.nodes, box);
                 uint32_t prim = push_prim(DP_TRIANGLE | (attr << 8), (uint32_t)material, rank_base + (uint32_t)(c - 1), g, top,
                                           M.tri_ids ? M.tri_ids[c - 1] : c - 1);
-                set_leaf(H.nodes, idx, prim);
-                set_skip(H.nodes, idx);
+                // The triangle's own bounds, padded: the barycentric test of src/triangle.jl:73-91 accepts points a few
+                // rounding errors outside the exact triangle, and the box must not cull those.
+                float box[6], ext = 0.0f, mag = 0.0f;
+                for (int ax = 0; ax < 3; ++ax) {
+                    float lo = std::min(g[ax], std::min(g[3 + ax], g[6 + ax])), hi = std::max(g[ax], std::max(g[3 + ax], g[6 + ax]));
+                    box[ax] = lo; box[3 + ax] = hi;
+                    ext = std::max(ext, hi - lo);
+                    mag = std::max(mag, std::max(std::fabs(lo), std::fabs(hi)));
+                }
+                float pad = 1e-4f * ext + 4e-6f * mag;
+                // never larger than the box the reference walks for this triangle (the leaf's box)
+                const float* lb = T.node_bounds + 6 * (size_t)(id - 1);
+                for (int ax = 0; ax < 3; ++ax) {
+                    box[ax] = std::max(box[ax] - pad, std::min(lb[ax], box[ax]));
+                    box[3 + ax] = std::min(box[3 + ax] + pad, std::max(lb[3 + ax], box[3 + ax]));
+                }
+                add_item(items, box, prim, 0u);
             }
             return true;
         }
         if (T.node_leaf[id - 1] != 0) return fail(RT_EINVAL, "reached an unused BVH node slot");
-        size_t idx = H.nodes.size() / 2;
-        push_node(H.nodes, box);
-        if (!emit_tris(T, M, top, T.node_left[id - 1], depth + 1, rank_base)) return false;
-        if (!emit_tris(T, M, top, T.node_right[id - 1], depth + 1, rank_base)) return false;
-        set_skip(H.nodes, idx);
-        return true;
+        return collect_tris(T, M, top, T.node_left[id - 1], depth + 1, rank_base, items) &&
+               collect_tris(T, M, top, T.node_right[id - 1], depth + 1, rank_base, items);
     }
-    bool emit_mesh_level(const rtBvh& T, int id, int depth, uint32_t rank_base, const std::vector<uint32_t>& rank_offset) {
+    bool collect_mesh_level(const rtBvh& T, int id, int depth, uint32_t rank_base, const std::vector<uint32_t>& rank_offset,
+                            std::vector<AccelItem>& items) {
         if (!check_node(T, id, depth)) return false;
         if (T.node_leaf[id - 1] > 1) return fail(RT_EINVAL, "reached an unused BVH node slot");
-        size_t idx = H.nodes.size() / 2;
-        push_node(H.nodes, T.node_bounds + 6 * (size_t)(id - 1));
         if (T.node_leaf[id - 1]) {
             int pos = T.node_right[id - 1];
             if (pos < 1 || pos > T.n_objects) return fail(RT_EINVAL, "mesh position out of range");
@@ -292,13 +317,11 @@ struct Builder {
             if (!valid_obj(oi) || D.objects[oi].kind != RT_MESH) return fail(RT_EINVAL, "mesh tree over a non-mesh object");
             int mi = D.objects[oi].aux;
             if (mi < 0 || mi >= D.n_meshes) return fail(RT_EINVAL, "mesh index out of range");
-            if (!emit_tris(T, D.meshes[mi], top_pos[(size_t)oi], T.node_left[id - 1], depth + 1, rank_base + rank_offset[(size_t)(pos - 1)])) return false;
-        } else {
-            if (!emit_mesh_level(T, T.node_left[id - 1], depth + 1, rank_base, rank_offset)) return false;
-            if (!emit_mesh_level(T, T.node_right[id - 1], depth + 1, rank_base, rank_offset)) return false;
+            return collect_tris(T, D.meshes[mi], top_pos[(size_t)oi], T.node_left[id - 1], depth + 1,
+                                rank_base + rank_offset[(size_t)(pos - 1)], items);
         }
-        set_skip(H.nodes, idx);
-        return true;
+        return collect_mesh_level(T, T.node_left[id - 1], depth + 1, rank_base, rank_offset, items) &&
+               collect_mesh_level(T, T.node_right[id - 1], depth + 1, rank_base, rank_offset, items);
     }
 
     bool run() {
@@ -327,34 +350,50 @@ struct Builder {
         }
         std::vector<uint32_t> base((size_t)D.n_buckets, 0);
         for (int b = D.n_buckets - 2; b >= 0; --b) base[(size_t)b] = base[(size_t)b + 1] + totals[(size_t)b + 1];
-        // region 0: trees of surfaces; region 1: trees of constant media (walked after all surfaces)
+        // region 0: one tree over every surface; region 1: one tree over the constant media (walked after the surfaces)
+        std::vector<float4> main_nodes[8];
         uint32_t region_start = 0;
         for (int region = 0; region < 2; ++region) {
+            std::vector<AccelItem> items;
             for (int b = 0; b < D.n_buckets; ++b) {
                 const rtBvh& T = D.buckets[b];
                 int first = T.objects[0];
                 bool is_medium = valid_obj(first) && D.objects[first].kind == RT_CONSTANT_MEDIUM;
                 if (is_medium != (region == 1)) continue;
                 visited = 0;
-                bool ok = T.kind == 1 ? emit_mesh_level(T, 1, 0, base[(size_t)b], offsets[(size_t)b])
-                                      : emit_generic(T, 1, 0, H.nodes, base[(size_t)b], &offsets[(size_t)b], false, -1);
+                bool ok = T.kind == 1 ? collect_mesh_level(T, 1, 0, base[(size_t)b], offsets[(size_t)b], items)
+                                      : collect_generic(T, 1, 0, items, base[(size_t)b], &offsets[(size_t)b], false, -1);
                 if (!ok) return false;
             }
-            uint32_t region_end = (uint32_t)(H.nodes.size() / 2);
-            for (uint32_t i = region_start; i < region_end; ++i)
-                if (fbits(H.nodes[2 * (size_t)i].w) == region_end) H.nodes[2 * (size_t)i].w = bitsf(RT_NODE_END);
+            emit_tree(items, main_nodes);
+            uint32_t region_end = (uint32_t)(main_nodes[0].size() / 2);
+            for (int o = 0; o < 8; ++o)
+                for (uint32_t i = region_start; i < region_end; ++i)
+                    if (fbits(main_nodes[o][2 * (size_t)i].w) == region_end) main_nodes[o][2 * (size_t)i].w = bitsf(RT_NODE_END);
             if (region_end > region_start) (region == 0 ? H.surface_root : H.medium_root) = region_start;
             region_start = region_end;
         }
-        // append the nested trees behind the two regions
-        uint32_t main_count = (uint32_t)(H.nodes.size() / 2);
-        for (size_t i = 0; i < sub_nodes.size() / 2; ++i) {
-            uint32_t s = fbits(sub_nodes[2 * i].w);
-            if (s != RT_NODE_END_SUB) sub_nodes[2 * i].w = bitsf(s + main_count);
+        // the nested trees go behind the two regions; the eight layouts follow one another
+        const uint64_t main_count = main_nodes[0].size() / 2, sub_count = sub_nodes[0].size() / 2;
+        const uint64_t per_layout = main_count + sub_count;
+        if (8 * per_layout >= (uint64_t)RT_NODE_END_SUB) return fail(RT_EUNSUPPORTED, "too many BVH nodes");
+        H.nodes_per_layout = (uint32_t)per_layout;
+        H.nested = sub_count != 0;
+        H.nodes.reserve((size_t)(16 * per_layout));
+        for (int o = 0; o < 8; ++o) {
+            const uint32_t shift = (uint32_t)(o * per_layout);
+            for (size_t i = 0; i < main_count; ++i) {
+                uint32_t s = fbits(main_nodes[o][2 * i].w);
+                if (s != RT_NODE_END) main_nodes[o][2 * i].w = bitsf(s + shift);
+            }
+            for (size_t i = 0; i < sub_count; ++i) {
+                uint32_t s = fbits(sub_nodes[o][2 * i].w);
+                if (s != RT_NODE_END_SUB) sub_nodes[o][2 * i].w = bitsf(s + (uint32_t)main_count + shift);
+            }
+            H.nodes.insert(H.nodes.end(), main_nodes[o].begin(), main_nodes[o].end());
+            H.nodes.insert(H.nodes.end(), sub_nodes[o].begin(), sub_nodes[o].end());
         }
-        H.nodes.insert(H.nodes.end(), sub_nodes.begin(), sub_nodes.end());
-        for (uint32_t p : instance_prims) H.prims[3 * (size_t)p].w += main_count; // g0 holds the root as raw bits
-        if (H.nodes.size() / 2 >= RT_NODE_END_SUB) return fail(RT_EUNSUPPORTED, "too many BVH nodes");
+        for (uint32_t p : instance_prims) H.prims[3 * (size_t)p].w += (uint32_t)main_count; // g0 holds the root as raw bits
         return true;
     }
 };

@@ -10,7 +10,9 @@
 #include "rt_device.h"
 
 struct HostScene {
-    std::vector<float4> nodes; // 2 per node
+    std::vector<float4> nodes; // 2 per node; eight layouts of nodes_per_layout nodes each, one per ray octant
+    uint32_t nodes_per_layout = 0;
+    bool nested = false; // nested trees (Transform{BVHTree}) present
     std::vector<uint4> prims;  // 3 per primitive
     std::vector<float> xforms; // 24 per transform
     std::vector<uint4> materials;
