@@ -12,7 +12,7 @@ struct RtCameraDev { // same field order as rtCamera (src/camera.jl:3-14)
     float lens_radius, t0, t1;
 };
 
-struct PathPool { // per-slot path state, six float4 planes of n_slots entries each (see rt_kernels.hip)
+struct PathPool { // per-slot path state, five float4 planes of n_slots entries each (see rt_kernels.hip)
     float4* q;
     uint32_t n_slots;
 };

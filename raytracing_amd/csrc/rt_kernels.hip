@@ -870,7 +870,7 @@ __device__ __forceinline__ void camera_ray(const RtCameraDev& cam, const float* 
 // The frame is rendered wavefront style.  A *path* is one trace() call: pattern column k of pixel r (r = row-
 // major pixel index, j * width + i, j counted from the bottom like the loops of draw!).  Paths are numbered
 // p = (k - k_begin) * n_pixels + r inside the batch of columns [k_begin, k_end) being rendered.  A pool of
-// *slots* (PathPool, six float4 planes in HBM) holds the paths in flight; every bounce is two launches:
+// *slots* (PathPool, five float4 planes in HBM) holds the paths in flight; every bounce is two launches:
 //   rt_extend_kernel  closest hit of every slot's ray (persistent waves; a lane fetches the next slot as soon as
 //                     its ray is finished; node stepping and leaf tests run under a wave-wide vote)
 //   rt_shade_kernel   hit completion, emission, scatter; a slot whose path ended writes the path's radiance to
@@ -878,9 +878,11 @@ __device__ __forceinline__ void camera_ray(const RtCameraDev& cam, const float* 
 //                     by material type in LDS so that a wave shades one material.
 // rt_sum_kernel then adds each pixel's radiances in column order, the order of the sample loop of draw!
 // (src/Ray_Tracing.jl:82-89), so the image does not depend on scheduling.
-// plane 0: {origin, time}        plane 1: {direction, bits(depth)}   depth <= 0: the slot holds no ray
-// plane 2: {acc, bits(p)}        plane 3: {color, -}
-// plane 4: {t, bits(prim), bits(side|xform), bits(type)}   type: 1..5 material type of the hit, 6 = miss
+// plane 0: {origin, time}        plane 1: {direction, bits(depth | flag)}   depth == 0: the slot holds no ray
+// plane 2: {acc, bits(p)}        plane 3: {t, bits(prim), bits(side|xform), bits(type)}   type: 1..5 material type of
+// the hit, 6 = miss.   plane 4: {color, -}, only valid (and only touched) when DEPTH_HAS_COLOR is set in the depth word
+#define DEPTH_MASK 0x3FFFFFFFu
+#define DEPTH_HAS_COLOR 0x40000000u
 #define QP(pool, plane, slot) (pool).q[(size_t)(plane) * (pool).n_slots + (slot)]
 #define HIT_MISS 6u
 #define EXTEND_CHUNK 256u
@@ -909,7 +911,6 @@ __device__ __forceinline__ void start_path(const RtCameraDev& cam, const float* 
     QP(pool, 0, slot) = make_float4(o.x, o.y, o.z, time);
     QP(pool, 1, slot) = make_float4(d.x, d.y, d.z, __uint_as_float((uint32_t)P.max_depth));
     QP(pool, 2, slot) = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(p));
-    QP(pool, 3, slot) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // the first n_slots paths of the batch; sync[0] = slot dispenser, sync[1] = next unstarted path
@@ -918,14 +919,13 @@ __global__ void __launch_bounds__(256) rt_init_kernel(RtCameraDev cam, const flo
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= pool.n_slots) return;
     float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    QP(pool, 4, slot) = z;
+    QP(pool, 3, slot) = z;
     if (slot < P.n_paths && P.max_depth > 0) {
         start_path(cam, pattern, P, pool, slot, slot);
     } else {
         QP(pool, 0, slot) = z;
         QP(pool, 1, slot) = z; // depth 0: no ray
         QP(pool, 2, slot) = z;
-        QP(pool, 3, slot) = z;
     }
 }
 
@@ -975,7 +975,7 @@ __global__ void __launch_bounds__(256) rt_extend_kernel(DevScene S, RtRenderPara
             if (fin) { // publish the hit for the shade kernel
                 uint32_t type = HIT_MISS;
                 if (best.t != INF) type = S.materials[S.prims[3u * best.prim].y].x & 0xFFu;
-                QP(pool, 4, slot) = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(type));
+                QP(pool, 3, slot) = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(type));
                 if (COUNT) cnt.rays++;
                 busy = false;
             }
@@ -993,8 +993,7 @@ __global__ void __launch_bounds__(256) rt_extend_kernel(DevScene S, RtRenderPara
                         uint32_t sidx = cur + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                         if (sidx < end) {
                             float4 p1 = QP(pool, 1, sidx);
-                            int depth = (int)__float_as_uint(p1.w);
-                            if (depth > 0) {
+                            if ((__float_as_uint(p1.w) & DEPTH_MASK) != 0u) {
                                 float4 p0 = QP(pool, 0, sidx);
                                 slot = sidx;
                                 busy = true;
@@ -1074,8 +1073,8 @@ __global__ void __launch_bounds__(256) rt_extend_kernel(DevScene S, RtRenderPara
 }
 
 #define SHADE_BLOCK 1024
-// sync[0]: slot dispenser of rt_extend_kernel (reset here), sync[1]: next unstarted path, active: slots holding a
-// ray after this bounce
+// sync[0]: slot dispenser of rt_extend_kernel (reset here), sync[1]: next unstarted path, active: set to 1 if any
+// slot holds a ray after this bounce
 __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCameraDev cam, const float* __restrict__ pattern,
                                                                RtRenderParams P, PathPool pool, float4* __restrict__ radiance,
                                                                uint32_t* __restrict__ sync, uint32_t* __restrict__ active) {
@@ -1094,14 +1093,12 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
     // wave has a ray, so the medium test runs converged), then the material type of the final hit; 7 = nothing to shade
     uint32_t my_key = 7u;
     if (base + t < pool.n_slots) {
-        float4 q1 = QP(pool, 1, base + t);
-        int depth0 = (int)__float_as_uint(q1.w);
+        float4 q1 = QP(pool, 1, base + t), q2 = QP(pool, 2, base + t), q4 = QP(pool, 3, base + t);
+        int depth0 = (int)(__float_as_uint(q1.w) & DEPTH_MASK);
         if (depth0 > 0) {
-            float4 q4 = QP(pool, 4, base + t);
-            uint32_t p = __float_as_uint(QP(pool, 2, base + t).w);
             int i, j, n;
             RngKey key;
-            path_ident(P, p, i, j, n, key);
+            path_ident(P, __float_as_uint(q2.w), i, j, n, key);
             if (S.medium_root != RT_NODE_END) {
                 float4 q0 = QP(pool, 0, base + t);
                 key.bounce = (uint32_t)(P.max_depth - depth0);
@@ -1138,11 +1135,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
     // Phase 2, thread t on slot base + mine: the body of trace()'s loop after the hit
     uint32_t slot = base + mine;
     bool valid = slot < pool.n_slots;
-    float4 q1 = valid ? QP(pool, 1, slot) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    int depth = (int)__float_as_uint(q1.w);
+    float4 q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q0 = q1, q2 = q1;
+    if (valid) { q1 = QP(pool, 1, slot); q0 = QP(pool, 0, slot); q2 = QP(pool, 2, slot); }
+    const uint32_t depth_word = __float_as_uint(q1.w);
+    int depth = (int)(depth_word & DEPTH_MASK);
     bool done = false, cont = false;
     if (valid && depth > 0) {
-        float4 q0 = QP(pool, 0, slot), q2 = QP(pool, 2, slot), q3 = QP(pool, 3, slot), q4 = hits[mine];
+        float4 q4 = hits[mine];
         uint32_t p = __float_as_uint(q2.w);
         RngKey key;
         key.pixel = idents[mine].x;
@@ -1151,7 +1150,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
         key.bounce = (uint32_t)(P.max_depth - depth);
         PathState ps;
         ps.acc = mk3(q2.x, q2.y, q2.z);
-        ps.color = mk3(q3.x, q3.y, q3.z);
+        ps.color = mk3(0.0f, 0.0f, 0.0f);
+        if (depth_word & DEPTH_HAS_COLOR) {
+            float4 q3 = QP(pool, 4, slot);
+            ps.color = mk3(q3.x, q3.y, q3.z);
+        }
         ps.depth = depth;
         Closest best;
         best.t = q4.x; best.prim = __float_as_uint(q4.y); best.sx = __float_as_uint(q4.z); best.rank = 0u;
@@ -1162,10 +1165,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
             radiance[p] = make_float4(result.x, result.y, result.z, 0.0f);
         } else {
             cont = true;
+            // the colour is +0 until a path ends in every scene the reference can describe; it only takes memory
+            // traffic when it is not (non-finite throughput)
+            bool has_color = (__float_as_uint(ps.color.x) | __float_as_uint(ps.color.y) | __float_as_uint(ps.color.z)) != 0u;
             QP(pool, 0, slot) = make_float4(no.x, no.y, no.z, q0.w);
-            QP(pool, 1, slot) = make_float4(nd.x, nd.y, nd.z, __uint_as_float((uint32_t)ps.depth));
+            QP(pool, 1, slot) = make_float4(nd.x, nd.y, nd.z, __uint_as_float((uint32_t)ps.depth | (has_color ? DEPTH_HAS_COLOR : 0u)));
             QP(pool, 2, slot) = make_float4(ps.acc.x, ps.acc.y, ps.acc.z, q2.w);
-            QP(pool, 3, slot) = make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f);
+            if (has_color) QP(pool, 4, slot) = make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f);
         }
     }
     // slots whose path ended take the next unstarted paths: one atomic per workgroup
@@ -1196,7 +1202,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
     unsigned long long m = __ballot(cont);
     if ((t & 63u) == 0u && m) atomicAdd(&block_alive, (uint32_t)__popcll(m));
     __syncthreads();
-    if (t == 0u && block_alive) atomicAdd(active, block_alive);
+    if (t == 0u && block_alive) *active = 1u; // every writer stores the same value: no atomic needed
 }
 
 // accum[pixel] (+)= radiance of the pixel's paths of this batch, added in column order like the sample loop of draw!

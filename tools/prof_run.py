@@ -14,4 +14,6 @@ print("%s %d spp: %.4f s, %.2f Mpaths/s" % (name, spp, st.seconds, paths / st.se
       "rays/path %.3f nodes/ray %.2f prims/ray %.2f | lane utilisation: node loop %.3f prim tests %.3f bounce loop %.3f" % (
           st.rays / paths, st.node_visits / max(1, st.rays), st.prim_tests / max(1, st.rays),
           st.node_visits / max(1, 64 * st.node_wave_steps), st.prim_tests / max(1, 64 * st.prim_wave_steps),
-          st.rays / max(1, 64 * st.bounce_wave_steps)) if flags else "")
+          st.rays / max(1, 64 * st.bounce_wave_steps)) if flags & 1 else "",
+      "| extend %.4f s in %d launches, shade %.4f s in %d launches" % (
+          st.extend_seconds, st.extend_launches, st.shade_seconds, st.shade_launches) if flags & 2 else "")
