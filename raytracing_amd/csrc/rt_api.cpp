@@ -43,7 +43,8 @@ struct rtScene {
     float4* d_radiance = nullptr; size_t radiance_cap = 0; // one entry per path of the batch in flight
     float4* d_pool = nullptr;   size_t pool_cap = 0;   // path state planes of the wavefront renderer
     uint32_t* d_sync = nullptr;                        // [0] slot dispenser head, [1..] active-slot counts per bounce
-    uint32_t* h_sync = nullptr;                        // pinned mirror of the active counts
+    uint32_t* h_sync = nullptr;                        // pinned mirror of the activity flag
+    uint32_t h_init[RT_SYNC_WORDS];                    // staging of the initial sync array
     int n_cus = 0;
     float* d_accum = nullptr;   size_t accum_cap = 0;
     unsigned long long* d_counters = nullptr;
@@ -54,7 +55,7 @@ struct rtScene {
     uint64_t last_extend_launches = 0, last_shade_launches = 0;
 };
 
-#define SYNC_WORDS 4096u   // word 0: slot dispenser; words 1..: ring of per-bounce active counts
+#define SYNC_WORDS RT_SYNC_WORDS // word 0: slot dispenser; words 2..: per-bounce activity flags; then the path dispensers
 #define BOUNCE_BATCH 16u   // bounces enqueued between two looks at the active count
 
 namespace {
@@ -215,7 +216,10 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
     // Slots in flight: enough rays per launch to fill the machine many times over (default 4 M).
     PathPool pool;
     uint64_t total_paths = (uint64_t)P.n_pixels * n_shard_samples;
-    pool.n_slots = (uint32_t)env_int("RT_AMD_SLOTS", 4 * 1024 * 1024);
+    // A multiple of 16 Ki, so that the paths the slots start with cover whole rounds of the path dispensers.
+    const uint32_t slot_quantum = RT_DISP_UNIT * RT_DISP_MAX;
+    pool.n_slots = (uint32_t)env_int("RT_AMD_SLOTS", 4 * 1024 * 1024) / slot_quantum * slot_quantum;
+    if (pool.n_slots < slot_quantum) pool.n_slots = slot_quantum;
     if ((uint64_t)pool.n_slots > total_paths) pool.n_slots = (uint32_t)((total_paths + 1023ull) / 1024ull * 1024ull);
     // The radiance of every path is kept until its pixel is summed, so the frame is cut into batches of pattern
     // columns whose radiance buffer fits the budget (default 12 GiB of the 288 GB).
@@ -250,9 +254,17 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
         P.k_begin = k0;
         P.k_end = k0 + (uint32_t)cols < n_shard_samples ? k0 + (uint32_t)cols : n_shard_samples;
         P.n_paths = (P.k_end - P.k_begin) * P.n_pixels;
-        // sync[0] = slot dispenser, sync[1] = next unstarted path, sync[2..] = active slots after each bounce
-        uint32_t init_sync[2] = {0u, pool.n_slots < P.n_paths ? pool.n_slots : P.n_paths};
-        HIP_TRY(hipMemcpyAsync(s->d_sync, init_sync, sizeof(init_sync), hipMemcpyHostToDevice, stream));
+        // sync[0] = slot dispenser, sync[2..] = activity flag of each bounce, then the path dispensers.  The slots
+        // start with paths 0 .. n_slots-1, which is the same number of whole units from every dispenser.
+        const uint32_t shade_blocks = (pool.n_slots + 1023u) / 1024u;
+        P.n_disp = shade_blocks < RT_DISP_MAX ? shade_blocks : RT_DISP_MAX;
+        const uint32_t n_units = (P.n_paths + RT_DISP_UNIT - 1u) / RT_DISP_UNIT;
+        P.disp_limit = (n_units + P.n_disp - 1u) / P.n_disp * RT_DISP_UNIT;
+        uint32_t disp_start = P.disp_limit; // nothing left to hand out
+        if (P.n_paths > pool.n_slots) disp_start = pool.n_slots / P.n_disp;
+        std::memset(s->h_init, 0, SYNC_WORDS * sizeof(uint32_t));
+        for (uint32_t c = 0; c < RT_DISP_MAX; ++c) s->h_init[RT_DISP_BASE + c * RT_DISP_STRIDE] = disp_start;
+        HIP_TRY(hipMemcpyAsync(s->d_sync, s->h_init, SYNC_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         // with max_depth == 0 trace() returns black without looking at the scene: no path ever writes its radiance
         if (P.max_depth == 0) HIP_TRY(hipMemsetAsync(s->d_radiance, 0, (size_t)P.n_paths * sizeof(float4), stream));
         rt_launch_init(&cam, s->d_pattern, &P, &pool, stream);

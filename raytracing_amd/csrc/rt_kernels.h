@@ -12,6 +12,12 @@ struct RtCameraDev { // same field order as rtCamera (src/camera.jl:3-14)
     float lens_radius, t0, t1;
 };
 
+#define RT_DISP_MAX 64u    // path dispensers at most
+#define RT_DISP_UNIT 256u  // consecutive paths dealt to one dispenser
+#define RT_DISP_BASE 64u   // first dispenser word in the sync array
+#define RT_DISP_STRIDE 32u // words between dispensers (128 bytes)
+#define RT_SYNC_WORDS (RT_DISP_BASE + RT_DISP_MAX * RT_DISP_STRIDE)
+
 struct PathPool { // per-slot path state, five float4 planes of n_slots entries each (see rt_kernels.hip)
     float4* q;
     uint32_t n_slots;
@@ -25,6 +31,7 @@ struct RtRenderParams {
     uint32_t n_paths;                // (k_end - k_begin) * n_pixels
     uint32_t seed32;
     float background[3];
+    uint32_t n_disp, disp_limit;     // path dispensers in use; local index at which a dispenser has run dry
     uint32_t leaf_threshold;         // wave vote: test queued leaves once this many lanes hold one
     uint32_t blocked_threshold;      // ... or once this many lanes cannot step before their leaves are tested
     uint32_t fetch_threshold;        // extend kernel: refill the wave once this many lanes are idle

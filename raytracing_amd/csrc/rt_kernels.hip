@@ -881,6 +881,11 @@ __device__ __forceinline__ void camera_ray(const RtCameraDev& cam, const float* 
 // plane 0: {origin, time}        plane 1: {direction, bits(depth | flag)}   depth == 0: the slot holds no ray
 // plane 2: {acc, bits(p)}        plane 3: {t, bits(prim), bits(side|xform), bits(type)}   type: 1..5 material type of
 // the hit, 6 = miss.   plane 4: {color, -}, only valid (and only touched) when DEPTH_HAS_COLOR is set in the depth word
+// Path dispensers (words of the sync array): counter c hands out local indices v; units of DISP_UNIT consecutive paths
+// are dealt round-robin to the counters, so every counter covers the whole batch evenly.
+#define DISP_BASE RT_DISP_BASE
+#define DISP_STRIDE RT_DISP_STRIDE
+#define DISP_UNIT RT_DISP_UNIT
 #define DEPTH_MASK 0x3FFFFFFFu
 #define DEPTH_HAS_COLOR 0x40000000u
 #define QP(pool, plane, slot) (pool).q[(size_t)(plane) * (pool).n_slots + (slot)]
@@ -899,6 +904,10 @@ __device__ __forceinline__ void path_ident(const RtRenderParams& P, uint32_t p, 
     key.seed32 = P.seed32;
 }
 
+__device__ __forceinline__ uint32_t dispensed_path(const RtRenderParams& P, uint32_t c, uint32_t v) {
+    return ((v / DISP_UNIT) * P.n_disp + c) * DISP_UNIT + (v % DISP_UNIT);
+}
+
 // camera ray of path p into slot `slot`
 __device__ __forceinline__ void start_path(const RtCameraDev& cam, const float* pattern, const RtRenderParams& P,
                                            PathPool& pool, uint32_t slot, uint32_t p) {
@@ -913,7 +922,7 @@ __device__ __forceinline__ void start_path(const RtCameraDev& cam, const float* 
     QP(pool, 2, slot) = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(p));
 }
 
-// the first n_slots paths of the batch; sync[0] = slot dispenser, sync[1] = next unstarted path
+// the first n_slots paths of the batch go to the slots directly (path p = slot)
 __global__ void __launch_bounds__(256) rt_init_kernel(RtCameraDev cam, const float* __restrict__ pattern, RtRenderParams P,
                                                       PathPool pool) {
     uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1073,8 +1082,8 @@ __global__ void __launch_bounds__(256) rt_extend_kernel(DevScene S, RtRenderPara
 }
 
 #define SHADE_BLOCK 1024
-// sync[0]: slot dispenser of rt_extend_kernel (reset here), sync[1]: next unstarted path, active: set to 1 if any
-// slot holds a ray after this bounce
+// sync[0]: slot dispenser of rt_extend_kernel (reset here), sync[DISP_BASE + c * DISP_STRIDE]: path dispenser c,
+// active: set to 1 if any slot holds a ray after this bounce
 __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCameraDev cam, const float* __restrict__ pattern,
                                                                RtRenderParams P, PathPool pool, float4* __restrict__ radiance,
                                                                uint32_t* __restrict__ sync, uint32_t* __restrict__ active) {
@@ -1082,7 +1091,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
     __shared__ uint16_t order[SHADE_BLOCK];
     __shared__ float4 hits[SHADE_BLOCK];  // per slot of the block: {t, prim, side|xform, type} after the media
     __shared__ uint2 idents[SHADE_BLOCK]; // per slot of the block: {pixel, pattern column} of its path
-    __shared__ uint32_t block_alive, block_need, block_base;
+    __shared__ uint32_t block_alive, block_need, block_base, block_disp;
     const uint32_t t = threadIdx.x;
     const uint32_t base = blockIdx.x * SHADE_BLOCK;
     if (t < 8u) { hist[t] = 0u; }
@@ -1183,20 +1192,34 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
     }
     __syncthreads();
     if (t == 0u) {
-        // once every path of the batch has been handed out the counter is left alone, so it cannot wrap
+        // The unstarted paths are handed out by P.n_disp counters, each 128 bytes from the next, so that the requests of
+        // the workgroups do not queue up on one address.  A workgroup asks its own counter and, once that one has run
+        // dry, its neighbour's.  A counter is left alone after it passed its limit, so it cannot wrap.
         block_base = 0xFFFFFFFFu;
-        if (block_need && __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P.n_paths)
-            block_base = atomicAdd(&sync[1], block_need);
+        if (block_need) {
+            for (uint32_t k = 0; k < 2u && block_base == 0xFFFFFFFFu; ++k) {
+                uint32_t c = (blockIdx.x + k) % P.n_disp;
+                uint32_t* ctr = sync + DISP_BASE + c * DISP_STRIDE;
+                if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P.disp_limit) {
+                    uint32_t v = atomicAdd(ctr, block_need);
+                    if (v < P.disp_limit) { block_base = v; block_disp = c; }
+                }
+            }
+        }
     }
     __syncthreads();
     if (done) {
-        uint32_t p = block_base + wave_pos + (uint32_t)__popcll(m_done & ((1ull << (t & 63u)) - 1ull));
-        if (block_base != 0xFFFFFFFFu && p < P.n_paths) {
-            start_path(cam, pattern, P, pool, slot, p);
-            cont = true;
-        } else {
-            QP(pool, 1, slot) = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // no ray left for this slot
+        bool started = false;
+        if (block_base != 0xFFFFFFFFu) {
+            uint32_t v = block_base + wave_pos + (uint32_t)__popcll(m_done & ((1ull << (t & 63u)) - 1ull));
+            uint32_t p = dispensed_path(P, block_disp, v);
+            if (p < P.n_paths) {
+                start_path(cam, pattern, P, pool, slot, p);
+                cont = true;
+                started = true;
+            }
         }
+        if (!started) QP(pool, 1, slot) = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // no ray left for this slot
     }
     // number of slots that still hold a ray: the host stops launching bounces when it reaches zero
     unsigned long long m = __ballot(cont);

@@ -105,12 +105,18 @@ def test_edge_cases(scenes, monkeypatch):
     for W, H, p, depth in ((2, 2, pat[:, :1], 50), (9, 3, rt.MSAA_S16.astype(F), 50), (16, 16, pat, 1), (16, 16, pat, 2), (8, 8, pat, 0)):
         img, _ = dev.render(cam, p, bg, W, H, max_depth=depth)
         np.testing.assert_array_equal(bits(img), bits(ref.render(cam, p, bg, W, H, max_depth=depth)))
-    # few slots (every slot is reused many times) and a tiny radiance budget (several column batches): same image
+    # few slots (every slot is reused many times, the path dispensers hand out ragged last units) and a tiny radiance
+    # budget (several column batches): same image
     want = ref.render(cam, pat, bg, 40, 24)
-    monkeypatch.setenv("RT_AMD_SLOTS", "1024")
-    monkeypatch.setenv("RT_AMD_RADIANCE_MIB", "1")
-    img, _ = dev.render(cam, pat, bg, 40, 24)
-    np.testing.assert_array_equal(bits(img), bits(want))
+    big = ref.render(cam, pat, bg, 150, 110)
+    for slots, mib in (("1024", "1"), ("16384", "1"), ("49152", "12288")):
+        monkeypatch.setenv("RT_AMD_SLOTS", slots)
+        monkeypatch.setenv("RT_AMD_RADIANCE_MIB", mib)
+        img, _ = dev.render(cam, pat, bg, 40, 24)
+        np.testing.assert_array_equal(bits(img), bits(want))
+        img, st = dev.render(cam, pat, bg, 150, 110)
+        np.testing.assert_array_equal(bits(img), bits(big))
+        assert st.paths == 150 * 110 * 5
     monkeypatch.delenv("RT_AMD_SLOTS")
     monkeypatch.delenv("RT_AMD_RADIANCE_MIB")
     monkeypatch.setenv("RT_AMD_NO_REGROUP", "1")     # material regrouping only changes which lane shades which slot
