@@ -199,17 +199,41 @@ void accel_build(std::vector<AccelItem>& items, AccelTree& tree) {
     }
 }
 
-void accel_emit(const AccelTree& tree, int octant, std::vector<float4>& out) {
+// float -> IEEE half, rounded toward -infinity (up = false) or +infinity (up = true); NaN gives the infinity of the
+// rounding direction, so a box with a NaN bound stays unconstrained on that side
+uint16_t accel_half(float x, bool up) {
+    if (!(x == x)) return up ? 0x7C00u : 0xFC00u;
+    _Float16 hf = (_Float16)x; // round to nearest even
+    uint16_t h;
+    std::memcpy(&h, &hf, 2);
+    float back = (float)hf;
+    if (up && back < x) {        // one step toward +infinity
+        if (h == 0x8000u) h = 0x0001u;
+        else if (h & 0x8000u) h -= 1u;
+        else h += 1u;
+    } else if (!up && back > x) { // one step toward -infinity
+        if (h == 0x0000u) h = 0x8001u;
+        else if (h & 0x8000u) h += 1u;
+        else h -= 1u;
+    }
+    return h;
+}
+
+void accel_emit(const AccelTree& tree, int octant, float scale, std::vector<uint4>& out) {
     if (tree.nodes.empty()) return;
-    auto bitsf = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+    auto pack = [scale](const float* b, uint32_t word) {
+        uint16_t h[6];
+        for (int a = 0; a < 3; ++a) { h[a] = accel_half(b[a] * scale, false); h[3 + a] = accel_half(b[3 + a] * scale, true); }
+        return make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
+                          (uint32_t)h[4] | ((uint32_t)h[5] << 16), word);
+    };
     std::vector<int32_t> stack;
     stack.push_back(0);
     while (!stack.empty()) {
         const AccelNode& nd = tree.nodes[(size_t)stack.back()];
         stack.pop_back();
-        uint32_t idx = (uint32_t)(out.size() / 2);
-        out.push_back(make_float4(nd.b[0], nd.b[1], nd.b[2], bitsf(idx + nd.size)));
-        out.push_back(make_float4(nd.b[3], nd.b[4], nd.b[5], bitsf(nd.leaf)));
+        uint32_t idx = (uint32_t)out.size();
+        out.push_back(pack(nd.b, nd.leaf ? (RT_NODE_LEAF | nd.leaf) : idx + nd.size));
         if (nd.leaf == 0) {
             int first = (octant >> nd.axis) & 1; // negative direction: the upper child is nearer
             stack.push_back(nd.child[1 - first]);

@@ -172,9 +172,13 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     }
     if (st != RT_OK) { rt_scene_destroy(s); return st; }
     s->dev.n_nodes = H.nodes_per_layout;
+    s->dev.node_scale = H.node_scale;
+    s->dev.inv_node_scale = 1.0f / H.node_scale;
     s->dev.n_prims = (uint32_t)(H.prims.size() / 3);
     s->dev.surface_root = H.surface_root;
+    s->dev.surface_size = H.surface_size;
     s->dev.medium_root = H.medium_root;
+    s->dev.medium_size = H.medium_size;
     s->dev.nested = H.nested ? 1u : 0u;
     *out = s;
     return RT_OK;

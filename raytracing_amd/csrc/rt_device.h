@@ -2,16 +2,17 @@
 // and the gfx950 kernels (rt_kernels.hip).
 //
 // Layout in HBM (scenes of the size the reference ships stay L2-resident):
-//   nodes   : 32 B per node = 2 x float4:  {min.xyz, bits(skip)}, {max.xyz, bits(leaf)}
-//             Nodes are stored in depth-first pre-order.  Traversal is stackless: a node whose box is
-//             hit continues at node+1 (its first child) and every other case continues at `skip`
-//             (the next node in pre-order that is not a descendant).  leaf = (primitive index + 1) |
-//             RT_LEAF_INSTANCE for nested trees, 0 for interior nodes.  One tree covers every surface of the
-//             SceneManager (its chain ends in RT_NODE_END), a second one the constant media, and the nested
-//             trees (Transform{BVHTree}) follow (their chains end in RT_NODE_END_SUB).  The whole array exists
-//             eight times, once per octant of ray directions, with the children of every node ordered near
-//             side first for that octant: layout o occupies nodes [o * n_nodes, (o + 1) * n_nodes) and its
-//             skip links stay inside it; roots are given relative to the layout.
+//   nodes   : 16 B per node = one uint4: the box as six IEEE halves (x: min.x | min.y << 16, y: min.z | max.x << 16,
+//             z: max.y | max.z << 16) of the bounds times node_scale, rounded outward, and a link word w:
+//             leaves carry RT_NODE_LEAF | (primitive index + 1) | RT_LEAF_INSTANCE for nested trees, interior nodes
+//             the skip link.  Nodes are stored in depth-first pre-order.  Traversal is stackless: an interior node
+//             whose box is hit continues at node+1 (its first child), one that is missed at its skip link (the next
+//             node in pre-order that is not a descendant); a leaf always continues at node+1.  The walk of a tree is
+//             over when it reaches the index one past the tree's last node.  One tree covers every surface of the
+//             SceneManager, a second one the constant media, and the nested trees (Transform{BVHTree}) follow.  The
+//             whole array exists eight times, once per octant of ray directions, with the children of every node
+//             ordered near side first for that octant: layout o occupies nodes [o * n_nodes, (o + 1) * n_nodes) and
+//             its skip links stay inside it; roots are given relative to the layout.
 //   prims   : 48 B per primitive = 3 x uint4: {head, material, rank, g0}, {g1..g4}, {g5..g8}
 //             head = kind (bits 0-3) | medium flag (bit 4) | index field (bits 8-31):
 //             transform index + 1 (0 = none), or for triangles the attribute record index.
@@ -20,9 +21,9 @@
 #define RT_DEVICE_H
 #include <stdint.h>
 
-#define RT_NODE_END 0xFFFFFFFFu     // traversal finished
-#define RT_NODE_END_SUB 0xFFFFFFFEu // end of a nested tree: restore the outer ray
-#define RT_LEAF_INSTANCE 0x80000000u // leaf word flag: the primitive is a nested tree (Transform{BVHTree})
+#define RT_NODE_NONE 0xFFFFFFFFu    // "no node" (e.g. no outer tree to return to)
+#define RT_NODE_LEAF 0x80000000u    // node link word: the node is a leaf
+#define RT_LEAF_INSTANCE 0x40000000u // leaf word flag: the primitive is a nested tree (Transform{BVHTree})
 
 enum DevPrimKind {
     DP_SPHERE = 1,
@@ -35,6 +36,7 @@ enum DevPrimKind {
     DP_INSTANCE = 8
 };
 #define DP_MEDIUM_FLAG 16u
+#define DP_TYPE_MASK 0xE0u // primitive head bits 5-7: material type of the primitive (1..5)
 
 #define DM_NEEDS_UV 0x100 // material type word: texture lookup reads u,v (image textures)
 
@@ -43,7 +45,7 @@ struct DevImage {
 };
 
 struct DevScene {
-    const float4* nodes;
+    const uint4* nodes;
     const uint4* prims;
     const float* xforms;
     const uint4* materials;      // {type | flags, texture, bits(fuzz), bits(eta)}
@@ -56,9 +58,10 @@ struct DevScene {
     const int32_t* prim_top;     // per primitive: position in the world vector (reported prim_id)
     const int32_t* prim_sub;     // per primitive: reported sub id base (triangle id / nested object index)
     uint32_t n_nodes, n_prims; // n_nodes: nodes per octant layout
-    uint32_t surface_root; // root of the surface tree (layout-relative), RT_NODE_END if there are no surfaces
+    float node_scale, inv_node_scale; // power of two applied to the node boxes (and to the ray for the box test)
+    uint32_t surface_root, surface_size; // root of the surface tree (layout-relative) and its node count (0: no surfaces)
     uint32_t nested;       // 1 if the scene holds nested trees (Transform{BVHTree})
-    uint32_t medium_root;  // root of the constant-medium tree (layout-relative), RT_NODE_END if there are no media
+    uint32_t medium_root, medium_size;   // the same for the tree of constant media
 };
 
 #endif

@@ -312,7 +312,7 @@ __device__ __forceinline__ float surface_t(const DevScene& S, uint32_t kind, uin
 struct Closest {
     float t;
     uint32_t prim; // primitive index
-    uint32_t sx;   // box side (bits 0-2) | (transform index + 1) << 3
+    uint32_t sx;   // box side (bits 0-2) | (transform index + 1) << 3 | material type << 29
     uint32_t rank; // tie-break: higher wins among equal t
 };
 struct Counters {
@@ -322,6 +322,22 @@ struct Counters {
 __device__ __forceinline__ uint32_t first_active_lane() {
     unsigned long long m = __ballot(1);
     return (uint32_t)(__ffsll((long long)m) - 1) == (threadIdx.x & 63u) ? 1u : 0u;
+}
+
+// The ray as the box test wants it: origin times the power of two the node boxes were scaled by, and 1/d divided by
+// it (scaling by a power of two is exact, so the distances come out as with unscaled boxes), paired up the way the six
+// half-precision bounds of a node are stored: (min.x, min.y) (min.z, max.x) (max.y, max.z).  The reciprocal is the
+// hardware approximation (1 ulp): the box test only culls, and its far distance is widened by more than that.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+struct BoxRay {
+    v2f o_xy, o_zx, o_yz, i_xy, i_zx, i_yz;
+};
+__device__ __forceinline__ void box_frame(const DevScene& S, f3 o, f3 d, BoxRay& R) {
+    f3 os = o * S.node_scale;
+    f3 is = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)) * S.inv_node_scale;
+    R.o_xy = (v2f){os.x, os.y}; R.o_zx = (v2f){os.z, os.x}; R.o_yz = (v2f){os.y, os.z};
+    R.i_xy = (v2f){is.x, is.y}; R.i_zx = (v2f){is.z, is.x}; R.i_yz = (v2f){is.y, is.z};
 }
 
 // Traversal of the flattened SceneManager.  Equivalent to hit(::SceneManager, ray, t_min, t_max)
@@ -338,11 +354,12 @@ __device__ __forceinline__ uint32_t first_active_lane() {
 // iteration the 64 lanes of the wave execute the one block that most lanes are waiting for, instead of each lane
 // dragging the whole wave through its own control flow.
 struct Walker {
-    f3 o, d, inv;              // ray in the frame being traversed (inv = 1/d for the box test)
+    f3 o, d;                   // ray in the frame being traversed
+    BoxRay R;                  // ... in the form the box test wants
     float time, t_min, t_max;  // t_max shrinks to the closest hit found so far
     f3 so, sd;                 // outer ray while inside a nested tree (a BVHTree inside a Transform)
-    uint32_t ret, inst_rank, inst_xf;
-    uint32_t node;             // next node to visit, RT_NODE_END / RT_NODE_END_SUB at the end of a tree
+    uint32_t ret, ret_end, inst_rank, inst_xf; // ret: node to continue at after a nested tree, RT_NODE_NONE outside one
+    uint32_t node, end;        // next node to visit; the walk of the current tree is over at node == end
     uint32_t leaf;             // pending leaf word: (primitive index + 1) | flags, 0 = none
     Closest best;
 };
@@ -354,17 +371,18 @@ __device__ __forceinline__ uint32_t layout_base(const DevScene& S, f3 d) {
 }
 __device__ __forceinline__ void walker_start(Walker& W, const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max) {
     W.o = o; W.d = d;
-    W.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    box_frame(S, o, d, W.R);
     W.time = time; W.t_min = t_min; W.t_max = t_max;
     W.so = o; W.sd = d;
-    W.ret = RT_NODE_END; W.inst_rank = 0; W.inst_xf = 0;
-    W.node = S.surface_root == RT_NODE_END ? RT_NODE_END : S.surface_root + layout_base(S, d);
+    W.ret = RT_NODE_NONE; W.ret_end = 0; W.inst_rank = 0; W.inst_xf = 0;
+    W.node = S.surface_root + layout_base(S, d);
+    W.end = W.node + S.surface_size;
     W.leaf = 0;
     W.best.t = INF; W.best.prim = 0xFFFFFFFFu; W.best.sx = 0; W.best.rank = 0;
 }
-__device__ __forceinline__ bool walker_finished(const Walker& W) { return W.leaf == 0u && W.node == RT_NODE_END; }
+__device__ __forceinline__ bool walker_finished(const Walker& W) { return W.leaf == 0u && W.node == W.end && W.ret == RT_NODE_NONE; }
 __device__ __forceinline__ bool walker_wants_leaf(const Walker& W) { return W.leaf != 0u; }
-__device__ __forceinline__ bool walker_wants_step(const Walker& W) { return W.leaf == 0u && W.node != RT_NODE_END; }
+__device__ __forceinline__ bool walker_wants_step(const Walker& W) { return W.leaf == 0u && !walker_finished(W); }
 
 __device__ __forceinline__ void consider(Closest& best, float& t_max, float t, uint32_t prim, uint32_t sx, uint32_t rank) {
     if (t < best.t || (t == best.t && t != INF && rank > best.rank)) {
@@ -454,62 +472,73 @@ __device__ __forceinline__ float medium_t(const DevScene& S, uint32_t head, cons
     return t1 + hit_distance / ray_length;
 }
 
-// One node: fetch + box test.  Call only for node < RT_NODE_END_SUB.
-__device__ __forceinline__ void node_step(const DevScene& S, const f3& o, const f3& inv, float t_min, float t_max,
-                                          uint32_t& node, uint32_t& leaf) {
-    float4 q0 = S.nodes[2u * node], q1 = S.nodes[2u * node + 1u];
-    // Box test (src/bounding_box.jl:70-84 form).  It only culls: the far distance is widened by 8 ulp so
-    // that rounding can never reject a box that the exact slab test of src/bounding_box.jl:20-67 accepts;
-    // NaNs (0 * Inf) drop out of fminf/fmaxf, which keeps the axis unconstrained.
-    float tx0 = (q0.x - o.x) * inv.x, tx1 = (q1.x - o.x) * inv.x;
-    float ty0 = (q0.y - o.y) * inv.y, ty1 = (q1.y - o.y) * inv.y;
-    float tz0 = (q0.z - o.z) * inv.z, tz1 = (q1.z - o.z) * inv.z;
-    float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t_min));
-    float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), t_max));
+// One node: fetch + box test.  `hit`: the ray passes the node's box inside (t_min, t_max); `link`: the node's link word
+// (leaf word with RT_NODE_LEAF set, or the skip link).  The walk continues at node + 1 after a leaf or a hit interior
+// node and at `link` after a missed interior node; it is over when it reaches the end index of its tree.
+__device__ __forceinline__ void node_test(const DevScene& S, const BoxRay& R, float t_min, float t_max, uint32_t node,
+                                          bool& hit, uint32_t& link) {
+    const uint4 q = S.nodes[node];
+    // Box test (src/bounding_box.jl:70-84 form).  It only culls: the stored boxes are rounded outward, and the far
+    // distance is widened by 8 ulp so that rounding can never reject a box that the exact slab test of
+    // src/bounding_box.jl:20-67 accepts; NaNs (0 * Inf) drop out of fminf/fmaxf, which keeps the axis unconstrained.
+    const v2f a = (__builtin_convertvector(__builtin_bit_cast(v2h, q.x), v2f) - R.o_xy) * R.i_xy; // x0, y0
+    const v2f b = (__builtin_convertvector(__builtin_bit_cast(v2h, q.y), v2f) - R.o_zx) * R.i_zx; // z0, x1
+    const v2f c = (__builtin_convertvector(__builtin_bit_cast(v2h, q.z), v2f) - R.o_yz) * R.i_yz; // y1, z1
+    float tnear = fmaxf(fmaxf(fminf(a.x, b.y), fminf(a.y, c.x)), fmaxf(fminf(b.x, c.y), t_min));
+    float tfar = fminf(fminf(fmaxf(a.x, b.y), fmaxf(a.y, c.x)), fminf(fmaxf(b.x, c.y), t_max));
     tfar = __builtin_fmaf(fabsf(tfar), 4.8e-7f, tfar);
-    uint32_t skip = __float_as_uint(q0.w);
-    uint32_t lf = __float_as_uint(q1.w);
-    bool hit = tnear <= tfar;
-    node = (hit && lf == 0u) ? node + 1u : skip;
-    leaf = hit ? lf : 0u;
+    hit = tnear <= tfar;
+    link = q.w;
+}
+__device__ __forceinline__ void node_step(const DevScene& S, const BoxRay& R, float t_min, float t_max, uint32_t& node,
+                                          uint32_t& leaf) {
+    bool hit;
+    uint32_t link;
+    node_test(S, R, t_min, t_max, node, hit, link);
+    const bool is_leaf = (int32_t)link < 0;
+    node = (hit || is_leaf) ? node + 1u : link;
+    leaf = (hit && is_leaf) ? (link & ~RT_NODE_LEAF) : 0u;
 }
 
 // The constant media of the scene for a ray whose closest surface is already in `best` (best.t = INF: none).
 // Every lane walks the (small) medium tree on its own; callers run this with all lanes of a wave active.
 __device__ __forceinline__ void media_closest(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max,
                                               const RngKey& key, Closest& best) {
-    if (S.medium_root == RT_NODE_END) return;
+    if (S.medium_size == 0u) return;
     uint32_t node = S.medium_root + layout_base(S, d);
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const uint32_t end = node + S.medium_size;
+    BoxRay R;
+    box_frame(S, o, d, R);
     if (best.t != INF) t_max = best.t;
-    while (node != RT_NODE_END) {
+    while (node != end) {
         uint32_t leaf;
-        node_step(S, o, inv, t_min, t_max, node, leaf);
+        node_step(S, R, t_min, t_max, node, leaf);
         if (leaf) {
             uint32_t prim = (leaf & ~RT_LEAF_INSTANCE) - 1u;
             uint4 head;
             Geom G;
             load_prim(S, prim, head, G);
             float t = medium_t(S, head.x, G.g, o, d, time, t_min, t_max, key);
-            consider(best, t_max, t, prim, (head.x >> 8) << 3, head.z);
+            consider(best, t_max, t, prim, ((head.x >> 8) << 3) | ((head.x & DP_TYPE_MASK) << 24), head.z);
         }
     }
 }
 
-// back out of a nested tree (node == RT_NODE_END_SUB): restore the outer ray
-__device__ __forceinline__ void walker_return(Walker& W) {
+// back out of a nested tree (its walk is over): restore the outer ray
+__device__ __forceinline__ void walker_return(Walker& W, const DevScene& S) {
     W.o = W.so; W.d = W.sd;
-    W.inv = mk3(1.0f / W.d.x, 1.0f / W.d.y, 1.0f / W.d.z);
-    W.node = W.ret;
+    box_frame(S, W.o, W.d, W.R);
+    W.node = W.ret; W.end = W.ret_end;
+    W.ret = RT_NODE_NONE;
     W.inst_rank = 0; W.inst_xf = 0;
 }
 
 template <bool COUNT>
 __device__ __forceinline__ void walker_step(Walker& W, const DevScene& S, Counters& cnt) {
-    if (W.node == RT_NODE_END_SUB) walker_return(W);
-    if (W.node < RT_NODE_END_SUB) {
+    if (W.node == W.end && W.ret != RT_NODE_NONE) walker_return(W, S);
+    if (W.node != W.end) {
         if (COUNT) cnt.nodes++;
-        node_step(S, W.o, W.inv, W.t_min, W.t_max, W.node, W.leaf);
+        node_step(S, W.R, W.t_min, W.t_max, W.node, W.leaf);
     }
 }
 
@@ -521,7 +550,7 @@ __device__ __forceinline__ void surface_leaf(const DevScene& S, uint32_t prim, c
     uint32_t kind = head.x & 15u;
     uint32_t side = 0, xf = inst_xf;
     float t = surface_t(S, kind, kind == DP_TRIANGLE ? 0u : head.x >> 8, G.g, o, d, time, t_min, t_max, side, xf);
-    consider(best, t_max, t, prim, side | (xf << 3), head.z + inst_rank);
+    consider(best, t_max, t, prim, side | (xf << 3) | ((head.x & DP_TYPE_MASK) << 24), head.z + inst_rank);
 }
 
 // The pending leaf primitive.  Call only for lanes with walker_wants_leaf().
@@ -537,16 +566,17 @@ __device__ __forceinline__ void walker_leaf(Walker& W, const DevScene& S, Counte
         // Transform{BVHTree}: src/transform.jl:104-116 around src/BVH.jl:22-53
         uint32_t field = head.x >> 8;
         W.so = W.o; W.sd = W.d;
-        W.ret = W.node;
+        W.ret = W.node; W.ret_end = W.end;
         W.inst_rank = head.z;
         W.inst_xf = field;
         if (field) {
             const float* T = S.xforms + 24u * (field - 1u) + 12;
             f3 no = apply_point(T, W.o), nd = apply_vec(T, W.d);
             W.o = no; W.d = nd;
-            W.inv = mk3(1.0f / nd.x, 1.0f / nd.y, 1.0f / nd.z);
         }
+        box_frame(S, W.o, W.d, W.R);
         W.node = __float_as_uint(G.g[0]) + layout_base(S, W.d);
+        W.end = W.node + __float_as_uint(G.g[1]);
         return;
     }
     surface_leaf(S, prim, head, G, W.o, W.d, W.time, W.t_min, W.t_max, W.inst_rank, W.inst_xf, W.best);
@@ -601,7 +631,7 @@ __device__ __forceinline__ void complete_hit(const DevScene& S, f3 o, f3 d, floa
     load_prim(S, best.prim, head, G);
     const float* g = G.g;
     uint32_t kind = head.x & 15u;
-    uint32_t side = best.sx & 7u, xf = best.sx >> 3;
+    uint32_t side = best.sx & 7u, xf = (best.sx >> 3) & 0x03FFFFFFu;
     float t = best.t;
     h.material = head.y;
     if (head.x & DP_MEDIUM_FLAG) { // src/constant_medium.jl:62-64
@@ -948,33 +978,36 @@ __global__ void __launch_bounds__(256) rt_init_kernel(RtCameraDev cam, const flo
 // trees (Transform{BVHTree}); without them the state for the outer ray is not carried.
 #define LEAF_QUEUE 3u
 template <bool COUNT, bool NESTED>
-__global__ void __launch_bounds__(256) rt_extend_kernel(DevScene S, RtRenderParams P, PathPool pool, uint32_t* __restrict__ head,
+__global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevScene S, RtRenderParams P, PathPool pool, uint32_t* __restrict__ head,
                                                         unsigned long long* __restrict__ counters) {
     const uint32_t lane = threadIdx.x & 63u;
     const float t_min = 0.001f;
     Counters cnt = {0, 0, 0, 0, 0, 0};
-    uint32_t cur = 0, end = 0; // wave-uniform cursor into the chunk of slots this wave owns
+    uint32_t cur = 0, cur_end = 0; // wave-uniform cursor into the chunk of slots this wave owns
     bool exhausted = false;
     bool busy = false;
     uint32_t slot = 0;
-    f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f), inv = mk3(0.0f, 0.0f, 1.0f);
+    f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
+    BoxRay R; // the ray in the form the box test wants
+    box_frame(S, o, d, R);
     float time = 0.0f, t_max = INF;
     f3 so = o, sd = d; // outer ray while inside a nested tree
-    uint32_t ret = RT_NODE_END, inst_rank = 0, inst_xf = 0;
-    uint32_t node = RT_NODE_END;
+    uint32_t ret = RT_NODE_NONE, ret_end = 0, inst_rank = 0, inst_xf = 0;
+    uint32_t node = 0, end = 0; // next node; the walk of the current tree is over at node == end
     uint32_t q0 = 0, q1 = 0, q2 = 0, nq = 0; // leaf queue: q0 newest; entry nq - 1 is the oldest
     Closest best = {INF, 0xFFFFFFFFu, 0u, 0u};
     for (;;) {
         // ---- end of a nested tree with nothing pending: back to the outer ray (cheap, no vote needed)
-        if (NESTED && busy && nq == 0u && node == RT_NODE_END_SUB) {
+        if (NESTED && busy && nq == 0u && node == end && ret != RT_NODE_NONE) {
             o = so; d = sd;
-            inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-            node = ret;
+            box_frame(S, o, d, R);
+            node = ret; end = ret_end;
+            ret = RT_NODE_NONE;
             inst_rank = 0; inst_xf = 0;
         }
-        const bool fin = busy && nq == 0u && node == RT_NODE_END;
+        const bool fin = busy && nq == 0u && node == end;
         const bool wl = busy && nq != 0u;
-        const bool ws = busy && node < RT_NODE_END_SUB && nq < LEAF_QUEUE && !(NESTED && nq != 0u && (q0 & RT_LEAF_INSTANCE));
+        const bool ws = busy && node != end && nq < LEAF_QUEUE && !(NESTED && nq != 0u && (q0 & RT_LEAF_INSTANCE));
         const uint32_t n_need = (uint32_t)__popcll(__ballot(!busy || fin));
         const uint32_t nl = (uint32_t)__popcll(__ballot(wl));
         const uint32_t ns = (uint32_t)__popcll(__ballot(ws));
@@ -982,42 +1015,42 @@ __global__ void __launch_bounds__(256) rt_extend_kernel(DevScene S, RtRenderPara
         // ---- retire finished rays and fetch new ones once enough lanes are idle
         if ((n_need >= P.fetch_threshold && !exhausted) || (nl | ns) == 0u) {
             if (fin) { // publish the hit for the shade kernel
-                uint32_t type = HIT_MISS;
-                if (best.t != INF) type = S.materials[S.prims[3u * best.prim].y].x & 0xFFu;
+                uint32_t type = best.t != INF ? best.sx >> 29 : HIT_MISS;
                 QP(pool, 3, slot) = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(type));
                 if (COUNT) cnt.rays++;
                 busy = false;
             }
             if (!exhausted) {
                 unsigned long long m = __ballot(!busy);
-                if (cur >= end) { // take the next chunk of slots
+                if (cur >= cur_end) { // take the next chunk of slots
                     uint32_t base = 0;
                     if (lane == 0u) base = atomicAdd(head, EXTEND_CHUNK);
                     base = (uint32_t)__shfl((int)base, 0);
-                    if (base >= pool.n_slots) { exhausted = true; cur = end = 0; }
-                    else { cur = base; end = min(base + EXTEND_CHUNK, pool.n_slots); }
+                    if (base >= pool.n_slots) { exhausted = true; cur = cur_end = 0; }
+                    else { cur = base; cur_end = min(base + EXTEND_CHUNK, pool.n_slots); }
                 }
                 if (!exhausted) {
                     if (!busy) {
                         uint32_t sidx = cur + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                        if (sidx < end) {
-                            float4 p1 = QP(pool, 1, sidx);
+                        if (sidx < cur_end) {
+                            float4 p1 = QP(pool, 1, sidx), p0 = QP(pool, 0, sidx);
                             if ((__float_as_uint(p1.w) & DEPTH_MASK) != 0u) {
-                                float4 p0 = QP(pool, 0, sidx);
                                 slot = sidx;
                                 busy = true;
                                 o = mk3(p0.x, p0.y, p0.z); d = mk3(p1.x, p1.y, p1.z);
-                                inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                                box_frame(S, o, d, R);
                                 time = p0.w;
                                 t_max = INF;
-                                node = S.surface_root == RT_NODE_END ? RT_NODE_END : S.surface_root + layout_base(S, d);
+                                node = S.surface_root + layout_base(S, d);
+                                end = node + S.surface_size;
                                 nq = 0u;
+                                ret = RT_NODE_NONE;
                                 inst_rank = 0; inst_xf = 0;
                                 best.t = INF; best.prim = 0xFFFFFFFFu; best.sx = 0u; best.rank = 0u;
                             }
                         }
                     }
-                    cur = min(cur + (uint32_t)__popcll(m), end);
+                    cur = min(cur + (uint32_t)__popcll(m), cur_end);
                 }
             }
             if (exhausted && __ballot(busy) == 0ull) break;
@@ -1040,16 +1073,17 @@ __global__ void __launch_bounds__(256) rt_extend_kernel(DevScene S, RtRenderPara
                     // the last one a lane queues, so the queue is empty now.
                     uint32_t field = hd.x >> 8;
                     so = o; sd = d;
-                    ret = node;
+                    ret = node; ret_end = end;
                     inst_rank = hd.z;
                     inst_xf = field;
                     if (field) {
                         const float* T = S.xforms + 24u * (field - 1u) + 12;
                         f3 no = apply_point(T, o), nd = apply_vec(T, d);
                         o = no; d = nd;
-                        inv = mk3(1.0f / nd.x, 1.0f / nd.y, 1.0f / nd.z);
                     }
+                    box_frame(S, o, d, R);
                     node = __float_as_uint(G.g[0]) + layout_base(S, d);
+                    end = node + __float_as_uint(G.g[1]);
                 } else {
                     surface_leaf(S, prim, hd, G, o, d, time, t_min, t_max, inst_rank, inst_xf, best);
                 }
@@ -1064,10 +1098,18 @@ __global__ void __launch_bounds__(256) rt_extend_kernel(DevScene S, RtRenderPara
             do {
                 if (stepping) {
                     if (COUNT) { cnt.nodes++; cnt.node_waves += first_active_lane(); }
-                    uint32_t leaf;
-                    node_step(S, o, inv, t_min, t_max, node, leaf);
-                    if (leaf != 0u) { q2 = q1; q1 = q0; q0 = leaf; nq += 1u; }
-                    stepping = node < RT_NODE_END_SUB && nq < LEAF_QUEUE && !(NESTED && (leaf & RT_LEAF_INSTANCE));
+                    bool hit;
+                    uint32_t link;
+                    node_test(S, R, t_min, t_max, node, hit, link);
+                    // branch-free bookkeeping: where the walk goes on, and the leaf queue (a shift register)
+                    const bool is_leaf = (int32_t)link < 0;
+                    const bool push = hit && is_leaf;
+                    node = (hit || is_leaf) ? node + 1u : link;
+                    q2 = push ? q1 : q2;
+                    q1 = push ? q0 : q1;
+                    q0 = push ? (link & ~RT_NODE_LEAF) : q0;
+                    nq += push ? 1u : 0u;
+                    stepping = node != end && nq < LEAF_QUEUE && !(NESTED && push && (link & RT_LEAF_INSTANCE));
                 }
             } while ((uint32_t)__popcll(__ballot(stepping)) >= floor_lanes);
         }
@@ -1108,17 +1150,15 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
             int i, j, n;
             RngKey key;
             path_ident(P, __float_as_uint(q2.w), i, j, n, key);
-            if (S.medium_root != RT_NODE_END) {
+            if (S.medium_size != 0u) {
                 float4 q0 = QP(pool, 0, base + t);
                 key.bounce = (uint32_t)(P.max_depth - depth0);
                 Closest best;
                 best.t = q4.x; best.prim = __float_as_uint(q4.y); best.sx = __float_as_uint(q4.z); best.rank = 0u;
                 uint32_t surface = best.prim;
                 media_closest(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, 0.001f, INF, key, best);
-                if (best.prim != surface) {
-                    uint32_t type = S.materials[S.prims[3u * best.prim].y].x & 0xFFu;
-                    q4 = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(type));
-                }
+                if (best.prim != surface)
+                    q4 = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(best.sx >> 29));
             }
             hits[t] = q4;
             idents[t] = make_uint2(key.pixel, key.sample);

@@ -24,8 +24,9 @@ struct Builder {
     std::string err;
     int status = RT_OK;
 
-    std::vector<float4> sub_nodes[8];         // nested trees (one copy per octant layout), relative indices
+    std::vector<uint4> sub_nodes[8];          // nested trees (one copy per octant layout), relative indices
     std::vector<int64_t> group_root;          // per group: relative root index in sub_nodes, -1 = not emitted
+    std::vector<uint32_t> group_size;         // per group: nodes in its tree
     std::vector<uint32_t> instance_prims;     // prims whose g0 holds a relative sub-tree root
     std::map<std::vector<uint32_t>, uint32_t> xform_index; // identical matrices share one device record
     std::vector<int> top_pos;                 // object index -> position in `top`
@@ -171,6 +172,7 @@ struct Builder {
                 int64_t root;
                 if (!emit_group(o->aux, top, root)) return false;
                 g[0] = bitsf((uint32_t)root);
+                g[1] = bitsf(group_size[(size_t)o->aux]);
                 out = push_prim(DP_INSTANCE | (xf << 8), 0u, rank, g, top, 0);
                 instance_prims.push_back(out);
                 return true;
@@ -186,7 +188,8 @@ struct Builder {
             material = o->material;
         }
         if (material < 0 || material >= D.n_materials) return fail(RT_EINVAL, "material index out of range");
-        out = push_prim(kind | (medium ? DP_MEDIUM_FLAG : 0u) | (xf << 8), (uint32_t)material, rank, g, top, sub);
+        uint32_t type = ((uint32_t)D.materials[material].type << 5) & DP_TYPE_MASK;
+        out = push_prim(kind | (medium ? DP_MEDIUM_FLAG : 0u) | type | (xf << 8), (uint32_t)material, rank, g, top, sub);
         return true;
     }
 
@@ -229,10 +232,11 @@ struct Builder {
 
     // Builds the device tree over `items` and appends its eight layouts to dst[0..7]; every layout gets the same
     // number of nodes, so one layout-relative root index serves all of them.
-    void emit_tree(std::vector<AccelItem>& items, std::vector<float4>* dst) {
+    void emit_tree(std::vector<AccelItem>& items, std::vector<uint4>* dst) {
+        if (items.empty()) return;
         AccelTree tree;
         accel_build(items, tree);
-        for (int o = 0; o < 8; ++o) accel_emit(tree, o, dst[o]);
+        for (int o = 0; o < 8; ++o) accel_emit(tree, o, H.node_scale, dst[o]);
     }
 
     bool emit_group(int gi, int top, int64_t& root) {
@@ -246,15 +250,35 @@ struct Builder {
         bool ok = collect_generic(T, 1, 0, items, 0u, nullptr, true, top);
         visited = saved;
         if (!ok) return false;
-        size_t start = sub_nodes[0].size() / 2;
+        size_t start = sub_nodes[0].size();
         emit_tree(items, sub_nodes);
-        size_t end = sub_nodes[0].size() / 2;
-        for (int o = 0; o < 8; ++o)
-            for (size_t i = start; i < end; ++i)
-                if (fbits(sub_nodes[o][2 * i].w) == (uint32_t)end) sub_nodes[o][2 * i].w = bitsf(RT_NODE_END_SUB);
         group_root[(size_t)gi] = (int64_t)start;
+        group_size[(size_t)gi] = (uint32_t)(sub_nodes[0].size() - start);
         root = (int64_t)start;
         return true;
+    }
+
+    // power of two that brings the largest finite box coordinate of the scene just below 2^15, well inside the range
+    // of the half-precision node boxes
+    void choose_node_scale() {
+        float m = 0.0f;
+        auto scan = [&m](const rtBvh& T) {
+            if (T.n_nodes <= 0 || !T.node_bounds) return;
+            for (int k = 0; k < 6; ++k) {
+                float v = std::fabs(T.node_bounds[k]);
+                if (std::isfinite(v) && v > m) m = v;
+            }
+        };
+        for (int b = 0; b < D.n_buckets; ++b) scan(D.buckets[b]);
+        for (int g = 0; g < D.n_groups; ++g) scan(D.groups[g]);
+        int k = 0;
+        if (m > 0.0f) {
+            int e;
+            std::frexp(m, &e); // m = f * 2^e, f in [0.5, 1)
+            k = 15 - e;
+        }
+        k = std::max(-100, std::min(100, k));
+        H.node_scale = std::ldexp(1.0f, k);
     }
 
     // tree over meshes (src/mesh.jl:250-283): every triangle becomes a primitive with its own bounding box
@@ -280,7 +304,8 @@ struct Builder {
                     a[9 + 2 * k] = v[6]; a[10 + 2 * k] = v[7];
                 }
                 H.tri_attr.insert(H.tri_attr.end(), a, a + 16);
-                uint32_t prim = push_prim(DP_TRIANGLE | (attr << 8), (uint32_t)material, rank_base + (uint32_t)(c - 1), g, top,
+                uint32_t type = ((uint32_t)D.materials[material].type << 5) & DP_TYPE_MASK;
+                uint32_t prim = push_prim(DP_TRIANGLE | type | (attr << 8), (uint32_t)material, rank_base + (uint32_t)(c - 1), g, top,
                                           M.tri_ids ? M.tri_ids[c - 1] : c - 1);
                 // The triangle's own bounds, padded: the barycentric test of src/triangle.jl:73-91 accepts points a few
                 // rounding errors outside the exact triangle, and the box must not cull those.
@@ -334,6 +359,7 @@ struct Builder {
             top_pos[(size_t)D.top[i]] = i;
         }
         group_root.assign((size_t)D.n_groups, -1);
+        group_size.assign((size_t)D.n_groups, 0u);
         // tie-break ranks: earlier type group wins, inside a group the later tree position wins
         std::vector<std::vector<uint32_t>> offsets((size_t)D.n_buckets);
         std::vector<uint32_t> totals((size_t)D.n_buckets, 0);
@@ -351,8 +377,8 @@ struct Builder {
         std::vector<uint32_t> base((size_t)D.n_buckets, 0);
         for (int b = D.n_buckets - 2; b >= 0; --b) base[(size_t)b] = base[(size_t)b + 1] + totals[(size_t)b + 1];
         // region 0: one tree over every surface; region 1: one tree over the constant media (walked after the surfaces)
-        std::vector<float4> main_nodes[8];
-        uint32_t region_start = 0;
+        choose_node_scale();
+        std::vector<uint4> main_nodes[8];
         for (int region = 0; region < 2; ++region) {
             std::vector<AccelItem> items;
             for (int b = 0; b < D.n_buckets; ++b) {
@@ -365,31 +391,27 @@ struct Builder {
                                       : collect_generic(T, 1, 0, items, base[(size_t)b], &offsets[(size_t)b], false, -1);
                 if (!ok) return false;
             }
+            uint32_t region_start = (uint32_t)main_nodes[0].size();
             emit_tree(items, main_nodes);
-            uint32_t region_end = (uint32_t)(main_nodes[0].size() / 2);
-            for (int o = 0; o < 8; ++o)
-                for (uint32_t i = region_start; i < region_end; ++i)
-                    if (fbits(main_nodes[o][2 * (size_t)i].w) == region_end) main_nodes[o][2 * (size_t)i].w = bitsf(RT_NODE_END);
-            if (region_end > region_start) (region == 0 ? H.surface_root : H.medium_root) = region_start;
-            region_start = region_end;
+            uint32_t region_size = (uint32_t)main_nodes[0].size() - region_start;
+            (region == 0 ? H.surface_root : H.medium_root) = region_start;
+            (region == 0 ? H.surface_size : H.medium_size) = region_size;
         }
         // the nested trees go behind the two regions; the eight layouts follow one another
-        const uint64_t main_count = main_nodes[0].size() / 2, sub_count = sub_nodes[0].size() / 2;
+        const uint64_t main_count = main_nodes[0].size(), sub_count = sub_nodes[0].size();
         const uint64_t per_layout = main_count + sub_count;
-        if (8 * per_layout >= (uint64_t)RT_NODE_END_SUB) return fail(RT_EUNSUPPORTED, "too many BVH nodes");
+        if (8 * per_layout >= (uint64_t)RT_NODE_LEAF - 1u) return fail(RT_EUNSUPPORTED, "too many BVH nodes");
+        if (H.prims.size() / 3 >= (size_t)RT_LEAF_INSTANCE - 1u) return fail(RT_EUNSUPPORTED, "too many primitives");
         H.nodes_per_layout = (uint32_t)per_layout;
         H.nested = sub_count != 0;
-        H.nodes.reserve((size_t)(16 * per_layout));
+        H.nodes.reserve((size_t)(8 * per_layout));
         for (int o = 0; o < 8; ++o) {
+            // skip links (interior nodes) become absolute; leaf words stay
             const uint32_t shift = (uint32_t)(o * per_layout);
-            for (size_t i = 0; i < main_count; ++i) {
-                uint32_t s = fbits(main_nodes[o][2 * i].w);
-                if (s != RT_NODE_END) main_nodes[o][2 * i].w = bitsf(s + shift);
-            }
-            for (size_t i = 0; i < sub_count; ++i) {
-                uint32_t s = fbits(sub_nodes[o][2 * i].w);
-                if (s != RT_NODE_END_SUB) sub_nodes[o][2 * i].w = bitsf(s + (uint32_t)main_count + shift);
-            }
+            for (uint4& n : main_nodes[o])
+                if (!(n.w & RT_NODE_LEAF)) n.w += shift;
+            for (uint4& n : sub_nodes[o])
+                if (!(n.w & RT_NODE_LEAF)) n.w += (uint32_t)main_count + shift;
             H.nodes.insert(H.nodes.end(), main_nodes[o].begin(), main_nodes[o].end());
             H.nodes.insert(H.nodes.end(), sub_nodes[o].begin(), sub_nodes[o].end());
         }

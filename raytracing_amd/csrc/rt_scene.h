@@ -10,8 +10,9 @@
 #include "rt_device.h"
 
 struct HostScene {
-    std::vector<float4> nodes; // 2 per node; eight layouts of nodes_per_layout nodes each, one per ray octant
+    std::vector<uint4> nodes;  // 1 per node; eight layouts of nodes_per_layout nodes each, one per ray octant
     uint32_t nodes_per_layout = 0;
+    float node_scale = 1.0f; // power of two the node boxes are multiplied by
     bool nested = false; // nested trees (Transform{BVHTree}) present
     std::vector<uint4> prims;  // 3 per primitive
     std::vector<float> xforms; // 24 per transform
@@ -23,7 +24,7 @@ struct HostScene {
     std::vector<float> perlin_vec;
     std::vector<int32_t> perlin_perm;
     std::vector<int32_t> prim_top, prim_sub;
-    uint32_t surface_root = RT_NODE_END, medium_root = RT_NODE_END;
+    uint32_t surface_root = 0, surface_size = 0, medium_root = 0, medium_size = 0; // layout-relative roots, node counts
 };
 
 // validates the description and fills `out`; returns an rtStatus and sets rt_last_error()
