@@ -148,8 +148,9 @@ typedef struct rtStats {
     uint64_t rays;        /* hit(scene, ray) calls; 0 unless RT_FLAG_COUNTERS */
     uint64_t node_visits; /* BVH nodes fetched and slab-tested; 0 unless RT_FLAG_COUNTERS */
     uint64_t prim_tests;  /* leaf primitive tests; 0 unless RT_FLAG_COUNTERS */
-    /* wave-level loop iterations of the three loops (64 lanes each): lane utilisation of a loop =
-     * per-lane events / (64 * wave steps).  0 unless RT_FLAG_COUNTERS */
+    /* wave-level executions (64 lanes each) of the three blocks of the extend kernel: node step, leaf test,
+     * retire/fetch.  Lane utilisation of a block = per-lane events / (64 * wave steps): node_visits, prim_tests
+     * and rays respectively.  0 unless RT_FLAG_COUNTERS */
     uint64_t node_wave_steps, prim_wave_steps, bounce_wave_steps;
     /* device time (HIP events on the launch stream) and launch counts of the two kernels of a bounce;
      * 0 unless RT_FLAG_TIMING */

@@ -148,6 +148,7 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     st = RT_OK;
     if (st == RT_OK) st = upload(s, H.nodes, &s->dev.nodes);
     if (st == RT_OK) st = upload(s, H.prims, &s->dev.prims);
+    if (st == RT_OK) st = upload(s, H.prim_inv, &s->dev.prim_inv);
     if (st == RT_OK) st = upload(s, H.xforms, &s->dev.xforms);
     if (st == RT_OK) st = upload(s, H.materials, &s->dev.materials);
     if (st == RT_OK) st = upload(s, H.textures, &s->dev.textures);

@@ -4,7 +4,7 @@
 // Layout in HBM (scenes of the size the reference ships stay L2-resident):
 //   nodes   : 16 B per node = one uint4: the box as six IEEE halves (x: min.x | min.y << 16, y: min.z | max.x << 16,
 //             z: max.y | max.z << 16) of the bounds times node_scale, rounded outward, and a link word w:
-//             leaves carry RT_NODE_LEAF | (primitive index + 1) | RT_LEAF_INSTANCE for nested trees, interior nodes
+//             leaves carry RT_NODE_LEAF | (primitive index + 1) | RT_LEAF_INSTANCE / RT_LEAF_XFORM flags, interior nodes
 //             the skip link.  Nodes are stored in depth-first pre-order.  Traversal is stackless: an interior node
 //             whose box is hit continues at node+1 (its first child), one that is missed at its skip link (the next
 //             node in pre-order that is not a descendant); a leaf always continues at node+1.  The walk of a tree is
@@ -24,6 +24,8 @@
 #define RT_NODE_NONE 0xFFFFFFFFu    // "no node" (e.g. no outer tree to return to)
 #define RT_NODE_LEAF 0x80000000u    // node link word: the node is a leaf
 #define RT_LEAF_INSTANCE 0x40000000u // leaf word flag: the primitive is a nested tree (Transform{BVHTree})
+#define RT_LEAF_XFORM 0x20000000u    // leaf word flag: the primitive sits in a Transform (prim_inv holds its inverse matrix)
+#define RT_LEAF_PRIM_MASK 0x1FFFFFFFu // leaf word: primitive index + 1
 
 enum DevPrimKind {
     DP_SPHERE = 1,
@@ -47,6 +49,7 @@ struct DevImage {
 struct DevScene {
     const uint4* nodes;
     const uint4* prims;
+    const float4* prim_inv;      // 3 per primitive: inverse 3x4 matrix (column-major) of its Transform, zeros without one
     const float* xforms;
     const uint4* materials;      // {type | flags, texture, bits(fuzz), bits(eta)}
     const uint4* textures;       // 2 per texture: {kind, a, b, 0}, {bits(color.xyz), bits(scale)}

@@ -258,7 +258,8 @@ __device__ __forceinline__ float triangle_t(const float* g, f3 o, f3 d, float t_
 // Distance to a surface primitive.  One code path per class so that a wave holding a mix of primitives does not
 // run one copy of the arithmetic per kind: spheres and moving spheres share sphere_t, the three rectangle kinds and
 // the six sides of a box share rect_t (ray components and bounds are selected per lane).
-__device__ __forceinline__ float surface_t(const DevScene& S, uint32_t kind, uint32_t field, const float* g, f3 o, f3 d,
+// Tinv: the inverse matrix of the Transform around the primitive (used when field != 0)
+__device__ __forceinline__ float surface_t(const float* Tinv, uint32_t kind, uint32_t field, const float* g, f3 o, f3 d,
                                            float time, float t_min, float t_max, uint32_t& side, uint32_t& xf) {
     side = 0;
     if (kind == DP_TRIANGLE) {
@@ -268,9 +269,8 @@ __device__ __forceinline__ float surface_t(const DevScene& S, uint32_t kind, uin
     }
     f3 ro = o, rd = d;
     if (field) { // Transform: src/transform.jl:104-105
-        const float* T = S.xforms + 24u * (field - 1u) + 12;
-        ro = apply_point(T, o);
-        rd = apply_vec(T, d);
+        ro = apply_point(Tinv, o);
+        rd = apply_vec(Tinv, d);
         xf = field;
     }
     if (kind <= DP_MOVING_SPHERE) {
@@ -514,7 +514,7 @@ __device__ __forceinline__ void media_closest(const DevScene& S, f3 o, f3 d, flo
         uint32_t leaf;
         node_step(S, R, t_min, t_max, node, leaf);
         if (leaf) {
-            uint32_t prim = (leaf & ~RT_LEAF_INSTANCE) - 1u;
+            uint32_t prim = (leaf & RT_LEAF_PRIM_MASK) - 1u;
             uint4 head;
             Geom G;
             load_prim(S, prim, head, G);
@@ -544,19 +544,19 @@ __device__ __forceinline__ void walker_step(Walker& W, const DevScene& S, Counte
 
 // One surface leaf for the ray (o, d) of the frame being walked.  A nested tree is entered (returns true, with the
 // new frame in `W`-style arguments handled by the caller); any other primitive is tested against `best`.
-__device__ __forceinline__ void surface_leaf(const DevScene& S, uint32_t prim, const uint4& head, const Geom& G, f3 o, f3 d,
+__device__ __forceinline__ void surface_leaf(const float* Tinv, uint32_t prim, const uint4& head, const Geom& G, f3 o, f3 d,
                                              float time, float t_min, float& t_max, uint32_t inst_rank, uint32_t inst_xf,
                                              Closest& best) {
     uint32_t kind = head.x & 15u;
     uint32_t side = 0, xf = inst_xf;
-    float t = surface_t(S, kind, kind == DP_TRIANGLE ? 0u : head.x >> 8, G.g, o, d, time, t_min, t_max, side, xf);
+    float t = surface_t(Tinv, kind, kind == DP_TRIANGLE ? 0u : head.x >> 8, G.g, o, d, time, t_min, t_max, side, xf);
     consider(best, t_max, t, prim, side | (xf << 3) | ((head.x & DP_TYPE_MASK) << 24), head.z + inst_rank);
 }
 
 // The pending leaf primitive.  Call only for lanes with walker_wants_leaf().
 template <bool COUNT>
 __device__ __forceinline__ void walker_leaf(Walker& W, const DevScene& S, Counters& cnt) {
-    uint32_t prim = (W.leaf & ~RT_LEAF_INSTANCE) - 1u;
+    uint32_t prim = (W.leaf & RT_LEAF_PRIM_MASK) - 1u;
     W.leaf = 0u;
     uint4 head;
     Geom G;
@@ -579,7 +579,8 @@ __device__ __forceinline__ void walker_leaf(Walker& W, const DevScene& S, Counte
         W.end = W.node + __float_as_uint(G.g[1]);
         return;
     }
-    surface_leaf(S, prim, head, G, W.o, W.d, W.time, W.t_min, W.t_max, W.inst_rank, W.inst_xf, W.best);
+    surface_leaf((const float*)(S.prim_inv + 3u * prim), prim, head, G, W.o, W.d, W.time, W.t_min, W.t_max, W.inst_rank,
+                 W.inst_xf, W.best);
 }
 
 // Wave-wide vote: which block should the wave run now?  0 = step, 1 = leaf, 2 = shade, 3 = nothing left.
@@ -1014,6 +1015,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
 
         // ---- retire finished rays and fetch new ones once enough lanes are idle
         if ((n_need >= P.fetch_threshold && !exhausted) || (nl | ns) == 0u) {
+            if (COUNT) cnt.bounce_waves += first_active_lane();
             if (fin) { // publish the hit for the shade kernel
                 uint32_t type = best.t != INF ? best.sx >> 29 : HIT_MISS;
                 QP(pool, 3, slot) = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(type));
@@ -1064,10 +1066,16 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                 if (COUNT) { cnt.prims++; cnt.prim_waves += first_active_lane(); }
                 uint32_t e = nq == 3u ? q2 : (nq == 2u ? q1 : q0);
                 nq -= 1u;
-                uint32_t prim = (e & ~RT_LEAF_INSTANCE) - 1u;
+                uint32_t prim = (e & RT_LEAF_PRIM_MASK) - 1u;
                 uint4 hd;
                 Geom G;
                 load_prim(S, prim, hd, G);
+                float Tinv[12] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                if (e & RT_LEAF_XFORM) { // issued together with the loads of the primitive
+                    float4 m0 = S.prim_inv[3u * prim], m1 = S.prim_inv[3u * prim + 1u], m2 = S.prim_inv[3u * prim + 2u];
+                    Tinv[0] = m0.x; Tinv[1] = m0.y; Tinv[2] = m0.z; Tinv[3] = m0.w; Tinv[4] = m1.x; Tinv[5] = m1.y;
+                    Tinv[6] = m1.z; Tinv[7] = m1.w; Tinv[8] = m2.x; Tinv[9] = m2.y; Tinv[10] = m2.z; Tinv[11] = m2.w;
+                }
                 if (NESTED && (e & RT_LEAF_INSTANCE)) {
                     // Transform{BVHTree}: src/transform.jl:104-116 around src/BVH.jl:22-53.  The flagged entry is
                     // the last one a lane queues, so the queue is empty now.
@@ -1085,7 +1093,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                     node = __float_as_uint(G.g[0]) + layout_base(S, d);
                     end = node + __float_as_uint(G.g[1]);
                 } else {
-                    surface_leaf(S, prim, hd, G, o, d, time, t_min, t_max, inst_rank, inst_xf, best);
+                    surface_leaf(Tinv, prim, hd, G, o, d, time, t_min, t_max, inst_rank, inst_xf, best);
                 }
             }
             continue;
@@ -1120,6 +1128,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
         atomicAdd(&counters[2], (unsigned long long)cnt.prims);
         atomicAdd(&counters[3], (unsigned long long)cnt.node_waves);
         atomicAdd(&counters[4], (unsigned long long)cnt.prim_waves);
+        atomicAdd(&counters[5], (unsigned long long)cnt.bounce_waves);
     }
 }
 

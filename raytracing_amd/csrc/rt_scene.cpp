@@ -117,6 +117,11 @@ struct Builder {
         H.prims.push_back(make_uint4(fbits(g[5]), fbits(g[6]), fbits(g[7]), fbits(g[8])));
         H.prim_top.push_back(top);
         H.prim_sub.push_back(sub);
+        // inverse matrix of the Transform around the primitive, next to it so that a leaf test needs one round of loads
+        uint32_t kind = head & 15u, field = head >> 8;
+        float m[12] = {0};
+        if (field && kind != DP_TRIANGLE) std::memcpy(m, &H.xforms[24 * (size_t)(field - 1) + 12], sizeof(m));
+        for (int k = 0; k < 3; ++k) H.prim_inv.push_back(make_float4(m[4 * k], m[4 * k + 1], m[4 * k + 2], m[4 * k + 3]));
         return idx;
     }
 
@@ -222,8 +227,10 @@ struct Builder {
             int top = nested ? nested_top : (valid_obj(oi) ? top_pos[(size_t)oi] : -1);
             uint32_t prim;
             if (!make_prim(oi, rank, top, nested ? oi : 0, nested, prim)) return false;
-            bool instance = (H.prims[3 * (size_t)prim].x & 15u) == DP_INSTANCE;
-            add_item(items, T.node_bounds + 6 * (size_t)(id - 1), prim, instance ? RT_LEAF_INSTANCE : 0u);
+            uint32_t head = H.prims[3 * (size_t)prim].x;
+            bool instance = (head & 15u) == DP_INSTANCE;
+            add_item(items, T.node_bounds + 6 * (size_t)(id - 1), prim,
+                     instance ? RT_LEAF_INSTANCE : ((head >> 8) ? RT_LEAF_XFORM : 0u));
             return true;
         }
         return collect_generic(T, T.node_left[id - 1], depth + 1, items, rank_base, rank_offset, nested, nested_top) &&
@@ -401,7 +408,7 @@ struct Builder {
         const uint64_t main_count = main_nodes[0].size(), sub_count = sub_nodes[0].size();
         const uint64_t per_layout = main_count + sub_count;
         if (8 * per_layout >= (uint64_t)RT_NODE_LEAF - 1u) return fail(RT_EUNSUPPORTED, "too many BVH nodes");
-        if (H.prims.size() / 3 >= (size_t)RT_LEAF_INSTANCE - 1u) return fail(RT_EUNSUPPORTED, "too many primitives");
+        if (H.prims.size() / 3 >= (size_t)RT_LEAF_PRIM_MASK) return fail(RT_EUNSUPPORTED, "too many primitives");
         H.nodes_per_layout = (uint32_t)per_layout;
         H.nested = sub_count != 0;
         H.nodes.reserve((size_t)(8 * per_layout));

@@ -15,6 +15,7 @@ struct HostScene {
     float node_scale = 1.0f; // power of two the node boxes are multiplied by
     bool nested = false; // nested trees (Transform{BVHTree}) present
     std::vector<uint4> prims;  // 3 per primitive
+    std::vector<float4> prim_inv; // 3 per primitive
     std::vector<float> xforms; // 24 per transform
     std::vector<uint4> materials;
     std::vector<uint4> textures; // 2 per texture

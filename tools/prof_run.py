@@ -11,7 +11,7 @@ dev = rt.DeviceScene(world)
 img, st = dev.render(kw["camera"], kw["pattern"], kw["background"], kw["width"], kw["height"], flags=flags)
 paths = kw["width"] * kw["height"] * spp
 print("%s %d spp: %.4f s, %.2f Mpaths/s" % (name, spp, st.seconds, paths / st.seconds / 1e6),
-      "rays/path %.3f nodes/ray %.2f prims/ray %.2f | lane utilisation: node loop %.3f prim tests %.3f bounce loop %.3f" % (
+      "rays/path %.3f nodes/ray %.2f prims/ray %.2f | lane utilisation: node steps %.3f leaf tests %.3f retire/fetch %.3f" % (
           st.rays / paths, st.node_visits / max(1, st.rays), st.prim_tests / max(1, st.rays),
           st.node_visits / max(1, 64 * st.node_wave_steps), st.prim_tests / max(1, 64 * st.prim_wave_steps),
           st.rays / max(1, 64 * st.bounce_wave_steps)) if flags & 1 else "",
