@@ -181,6 +181,7 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     s->dev.medium_root = H.medium_root;
     s->dev.medium_size = H.medium_size;
     s->dev.nested = H.nested ? 1u : 0u;
+    s->dev.textured = H.textured ? 1u : 0u;
     *out = s;
     return RT_OK;
 }

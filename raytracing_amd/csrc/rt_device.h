@@ -64,6 +64,7 @@ struct DevScene {
     float node_scale, inv_node_scale; // power of two applied to the node boxes (and to the ray for the box test)
     uint32_t surface_root, surface_size; // root of the surface tree (layout-relative) and its node count (0: no surfaces)
     uint32_t nested;       // 1 if the scene holds nested trees (Transform{BVHTree})
+    uint32_t textured;     // 1 if any texture is not a SolidColor
     uint32_t medium_root, medium_size;   // the same for the tree of constant media
 };
 

@@ -769,7 +769,14 @@ __device__ __forceinline__ float turbulence(const DevScene& S, uint32_t pi, f3 p
     return fabsf(accum);
 }
 
+// TEXTURED = false: every texture of the scene is a SolidColor (the host checked), so only that case is compiled in;
+// the noise and image code would otherwise set the register budget of the whole shade kernel.
+template <bool TEXTURED>
 __device__ __forceinline__ f3 texture_value(const DevScene& S, uint32_t ti, float u, float v, f3 p) {
+    if (!TEXTURED) {
+        uint4 b = S.textures[2u * ti + 1u];
+        return mk3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+    }
     // a checker nests two textures (src/texture.jl:46-53): resolve it iteratively
     for (int depth = 0; depth < 8; ++depth) {
         uint4 a = S.textures[2u * ti];
@@ -834,6 +841,7 @@ struct PathState {
 
 // The body of the while loop of trace() after hit(scene, ray) returned `best` for the ray (o, d, time).
 // Returns true when the path ended, with its radiance in `result`; otherwise (no, nd) is the scattered ray.
+template <bool TEXTURED>
 __device__ __forceinline__ bool shade(const DevScene& S, f3 o, f3 d, float time, const Closest& best, PathState& ps,
                                       f3 background, RngKey& key, f3& result, f3& no, f3& nd) {
     if (best.t == INF) { result = ps.color + ps.acc * background; return true; }
@@ -846,11 +854,11 @@ __device__ __forceinline__ bool shade(const DevScene& S, f3 o, f3 d, float time,
     if (type == 1u) { // Lambertian
         nd = h.n + normalize3(random_in_unit_sphere(key));
         if (is_zero3(nd)) nd = h.n;
-        att = texture_value(S, m.y, h.u, h.v, h.p);
+        att = texture_value<TEXTURED>(S, m.y, h.u, h.v, h.p);
     } else if (type == 2u) { // Metal
         f3 reflected = reflect3(normalize3(d), h.n);
         nd = reflected + __uint_as_float(m.z) * random_in_unit_sphere(key);
-        att = dot3(nd, h.n) > 0.0f ? texture_value(S, m.y, h.u, h.v, h.p) : mk3(0.0f, 0.0f, 0.0f);
+        att = dot3(nd, h.n) > 0.0f ? texture_value<TEXTURED>(S, m.y, h.u, h.v, h.p) : mk3(0.0f, 0.0f, 0.0f);
     } else if (type == 3u) { // Dielectric
         float eta = __uint_as_float(m.w);
         float ratio = h.front ? (1.0f / eta) : eta;
@@ -863,11 +871,11 @@ __device__ __forceinline__ bool shade(const DevScene& S, f3 o, f3 d, float time,
         att = mk3(1.0f, 1.0f, 1.0f);
     } else if (type == 5u) { // Isotropic
         nd = random_in_unit_sphere(key);
-        att = texture_value(S, m.y, h.u, h.v, h.p);
+        att = texture_value<TEXTURED>(S, m.y, h.u, h.v, h.p);
     } else { // Emissive: zero ray, zero attenuation (src/hittable.jl:72-74), emits on both faces (:77-83)
         nd = mk3(0.0f, 0.0f, 0.0f);
         att = mk3(0.0f, 0.0f, 0.0f);
-        emitted = texture_value(S, m.y, h.u, h.v, h.p);
+        emitted = texture_value<TEXTURED>(S, m.y, h.u, h.v, h.p);
     }
     ps.color = ps.color + ps.acc * emitted;
     if (is_zero3(att)) { result = ps.color; return true; }
@@ -905,7 +913,7 @@ __device__ __forceinline__ void camera_ray(const RtCameraDev& cam, const float* 
 //   rt_extend_kernel  closest hit of every slot's ray (persistent waves; a lane fetches the next slot as soon as
 //                     its ray is finished; node stepping and leaf tests run under a wave-wide vote)
 //   rt_shade_kernel   hit completion, emission, scatter; a slot whose path ended writes the path's radiance to
-//                     radiance[p] and takes the next unstarted path.  The 1024 slots of a workgroup are regrouped
+//                     radiance[p] and takes the next unstarted path.  The slots of a workgroup (SHADE_BLOCK) are regrouped
 //                     by material type in LDS so that a wave shades one material.
 // rt_sum_kernel then adds each pixel's radiances in column order, the order of the sample loop of draw!
 // (src/Ray_Tracing.jl:82-89), so the image does not depend on scheduling.
@@ -1132,9 +1140,10 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
     }
 }
 
-#define SHADE_BLOCK 1024
+#define SHADE_BLOCK 256
 // sync[0]: slot dispenser of rt_extend_kernel (reset here), sync[DISP_BASE + c * DISP_STRIDE]: path dispenser c,
 // active: set to 1 if any slot holds a ray after this bounce
+template <bool TEXTURED>
 __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCameraDev cam, const float* __restrict__ pattern,
                                                                RtRenderParams P, PathPool pool, float4* __restrict__ radiance,
                                                                uint32_t* __restrict__ sync, uint32_t* __restrict__ active) {
@@ -1217,7 +1226,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
         Closest best;
         best.t = q4.x; best.prim = __float_as_uint(q4.y); best.sx = __float_as_uint(q4.z); best.rank = 0u;
         f3 result, no, nd;
-        done = shade(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, best, ps,
+        done = shade<TEXTURED>(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, best, ps,
                      mk3(P.background[0], P.background[1], P.background[2]), key, result, no, nd);
         if (done) {
             radiance[p] = make_float4(result.x, result.y, result.z, 0.0f);
@@ -1372,7 +1381,7 @@ __global__ void __launch_bounds__(256) rt_trace_paths_kernel(DevScene S, RtCamer
             if (done) c = ps.color;
             else {
                 media_closest(S, W.o, W.d, W.time, 0.001f, INF, key, W.best);
-                done = shade(S, W.o, W.d, W.time, W.best, ps, bgc, key, c, no, nd);
+                done = shade<true>(S, W.o, W.d, W.time, W.best, ps, bgc, key, c, no, nd);
             }
             if (done) alive = false;
             else walker_start(W, S, no, nd, W.time, 0.001f, INF);
@@ -1400,8 +1409,10 @@ extern "C" void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, cons
     else if (nested) hipLaunchKernelGGL((rt_extend_kernel<false, true>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
     else hipLaunchKernelGGL((rt_extend_kernel<false, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
     if (timing) (void)hipEventRecord(timing[1], stream);
-    hipLaunchKernelGGL(rt_shade_kernel, dim3(shade_blocks), dim3(SHADE_BLOCK), 0, stream, *S, *cam, d_pattern, *P, *pool, d_radiance,
-                       d_sync, d_active);
+    if (S->textured) hipLaunchKernelGGL(rt_shade_kernel<true>, dim3(shade_blocks), dim3(SHADE_BLOCK), 0, stream, *S, *cam, d_pattern, *P, *pool,
+                                        d_radiance, d_sync, d_active);
+    else hipLaunchKernelGGL(rt_shade_kernel<false>, dim3(shade_blocks), dim3(SHADE_BLOCK), 0, stream, *S, *cam, d_pattern, *P, *pool,
+                            d_radiance, d_sync, d_active);
     if (timing) (void)hipEventRecord(timing[2], stream);
 }
 extern "C" void rt_launch_sum(const RtRenderParams* P, const float4* d_radiance, float* d_accum, int first_batch, hipStream_t stream) {

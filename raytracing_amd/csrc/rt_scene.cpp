@@ -51,6 +51,7 @@ struct Builder {
     bool tables() {
         for (int i = 0; i < D.n_textures; ++i) {
             const rtTexture& t = D.textures[i];
+            if (t.kind != RT_TEX_SOLID) H.textured = true;
             switch (t.kind) {
                 case RT_TEX_SOLID: break;
                 case RT_TEX_CHECKER:

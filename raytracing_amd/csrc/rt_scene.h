@@ -14,6 +14,7 @@ struct HostScene {
     uint32_t nodes_per_layout = 0;
     float node_scale = 1.0f; // power of two the node boxes are multiplied by
     bool nested = false; // nested trees (Transform{BVHTree}) present
+    bool textured = false; // a texture other than SolidColor present
     std::vector<uint4> prims;  // 3 per primitive
     std::vector<float4> prim_inv; // 3 per primitive
     std::vector<float> xforms; // 24 per transform
