@@ -233,6 +233,7 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
     uint64_t cols = budget / ((uint64_t)P.n_pixels * sizeof(float4));
     uint64_t max_cols = (0xFFFFFFFFull - pool.n_slots - 4096ull) / P.n_pixels; // path numbers are 32-bit
     if (cols > max_cols) cols = max_cols;
+    if (cols > 0xFFFFFFull) cols = 0xFFFFFFull; // the column inside the batch travels in 24 bits of the depth word
     if (cols > n_shard_samples) cols = n_shard_samples;
     if (cols < 1) return rt_fail(RT_EINVAL, "image too large for the radiance buffer budget");
     st = ensure(&s->d_pattern, &s->pattern_cap, (size_t)2 * (size_t)n);

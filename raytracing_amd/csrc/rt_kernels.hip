@@ -918,29 +918,29 @@ __device__ __forceinline__ void camera_ray(const RtCameraDev& cam, const float* 
 // rt_sum_kernel then adds each pixel's radiances in column order, the order of the sample loop of draw!
 // (src/Ray_Tracing.jl:82-89), so the image does not depend on scheduling.
 // plane 0: {origin, time}        plane 1: {direction, bits(depth | flag)}   depth == 0: the slot holds no ray
-// plane 2: {acc, bits(p)}        plane 3: {t, bits(prim), bits(side|xform), bits(type)}   type: 1..5 material type of
+// plane 2: {acc, bits(pixel)}        plane 3: {t, bits(prim), bits(side|xform), bits(type)}   type: 1..5 material type of
 // the hit, 6 = miss.   plane 4: {color, -}, only valid (and only touched) when DEPTH_HAS_COLOR is set in the depth word
 // Path dispensers (words of the sync array): counter c hands out local indices v; units of DISP_UNIT consecutive paths
 // are dealt round-robin to the counters, so every counter covers the whole batch evenly.
 #define DISP_BASE RT_DISP_BASE
 #define DISP_STRIDE RT_DISP_STRIDE
 #define DISP_UNIT RT_DISP_UNIT
-#define DEPTH_MASK 0x3FFFFFFFu
+// depth word of a slot: remaining depth (bits 0-5), pattern column of the path inside the batch (bits 6-29), colour flag
+#define DEPTH_MASK 0x3Fu
+#define DEPTH_COLUMN_SHIFT 6
+#define DEPTH_COLUMN_MASK 0xFFFFFFu
 #define DEPTH_HAS_COLOR 0x40000000u
 #define QP(pool, plane, slot) (pool).q[(size_t)(plane) * (pool).n_slots + (slot)]
 #define HIT_MISS 6u
 #define EXTEND_CHUNK 256u
 
-// path p -> pixel (i, j), pattern column n; fills the random-number key of the path
-__device__ __forceinline__ void path_ident(const RtRenderParams& P, uint32_t p, int& i, int& j, int& n, RngKey& key) {
-    uint32_t kk = p / P.n_pixels;
-    uint32_t r = p - kk * P.n_pixels;
-    j = (int)(r / (uint32_t)P.width);
-    i = (int)(r - (uint32_t)j * (uint32_t)P.width);
-    n = P.sample_first + (int)(P.k_begin + kk) * P.sample_stride;
+// random-number key of the path at pixel r (row-major) and column kk of the batch; returns the pattern column
+__device__ __forceinline__ int path_key(const RtRenderParams& P, uint32_t kk, uint32_t r, RngKey& key) {
+    int n = P.sample_first + (int)(P.k_begin + kk) * P.sample_stride;
     key.pixel = r;
     key.sample = (uint32_t)n;
     key.seed32 = P.seed32;
+    return n;
 }
 
 __device__ __forceinline__ uint32_t dispensed_path(const RtRenderParams& P, uint32_t c, uint32_t v) {
@@ -950,15 +950,19 @@ __device__ __forceinline__ uint32_t dispensed_path(const RtRenderParams& P, uint
 // camera ray of path p into slot `slot`
 __device__ __forceinline__ void start_path(const RtCameraDev& cam, const float* pattern, const RtRenderParams& P,
                                            PathPool& pool, uint32_t slot, uint32_t p) {
-    int i, j, n;
+    // the only place where a path number is taken apart (two divisions per path, none per bounce)
+    uint32_t kk = p / P.n_pixels;
+    uint32_t r = p - kk * P.n_pixels;
+    int j = (int)(r / (uint32_t)P.width);
+    int i = (int)(r - (uint32_t)j * (uint32_t)P.width);
     RngKey key;
-    path_ident(P, p, i, j, n, key);
+    int n = path_key(P, kk, r, key);
     f3 o, d;
     float time;
     camera_ray(cam, pattern, i, j, n, P.width, P.height, key, o, d, time);
     QP(pool, 0, slot) = make_float4(o.x, o.y, o.z, time);
-    QP(pool, 1, slot) = make_float4(d.x, d.y, d.z, __uint_as_float((uint32_t)P.max_depth));
-    QP(pool, 2, slot) = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(p));
+    QP(pool, 1, slot) = make_float4(d.x, d.y, d.z, __uint_as_float((uint32_t)P.max_depth | (kk << DEPTH_COLUMN_SHIFT)));
+    QP(pool, 2, slot) = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(r));
 }
 
 // the first n_slots paths of the batch go to the slots directly (path p = slot)
@@ -1150,7 +1154,6 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
     __shared__ uint32_t hist[8], cursor[8];
     __shared__ uint16_t order[SHADE_BLOCK];
     __shared__ float4 hits[SHADE_BLOCK];  // per slot of the block: {t, prim, side|xform, type} after the media
-    __shared__ uint2 idents[SHADE_BLOCK]; // per slot of the block: {pixel, pattern column} of its path
     __shared__ uint32_t block_alive, block_need, block_base, block_disp;
     const uint32_t t = threadIdx.x;
     const uint32_t base = blockIdx.x * SHADE_BLOCK;
@@ -1165,10 +1168,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
         float4 q1 = QP(pool, 1, base + t), q2 = QP(pool, 2, base + t), q4 = QP(pool, 3, base + t);
         int depth0 = (int)(__float_as_uint(q1.w) & DEPTH_MASK);
         if (depth0 > 0) {
-            int i, j, n;
-            RngKey key;
-            path_ident(P, __float_as_uint(q2.w), i, j, n, key);
             if (S.medium_size != 0u) {
+                RngKey key;
+                path_key(P, (__float_as_uint(q1.w) >> DEPTH_COLUMN_SHIFT) & DEPTH_COLUMN_MASK, __float_as_uint(q2.w), key);
                 float4 q0 = QP(pool, 0, base + t);
                 key.bounce = (uint32_t)(P.max_depth - depth0);
                 Closest best;
@@ -1179,7 +1181,6 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
                     q4 = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(best.sx >> 29));
             }
             hits[t] = q4;
-            idents[t] = make_uint2(key.pixel, key.sample);
             my_key = __float_as_uint(q4.w) & 7u;
         }
     }
@@ -1209,11 +1210,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
     bool done = false, cont = false;
     if (valid && depth > 0) {
         float4 q4 = hits[mine];
-        uint32_t p = __float_as_uint(q2.w);
+        const uint32_t kk = (depth_word >> DEPTH_COLUMN_SHIFT) & DEPTH_COLUMN_MASK, r = __float_as_uint(q2.w);
         RngKey key;
-        key.pixel = idents[mine].x;
-        key.sample = idents[mine].y;
-        key.seed32 = P.seed32;
+        path_key(P, kk, r, key);
         key.bounce = (uint32_t)(P.max_depth - depth);
         PathState ps;
         ps.acc = mk3(q2.x, q2.y, q2.z);
@@ -1229,14 +1228,14 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
         done = shade<TEXTURED>(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, best, ps,
                      mk3(P.background[0], P.background[1], P.background[2]), key, result, no, nd);
         if (done) {
-            radiance[p] = make_float4(result.x, result.y, result.z, 0.0f);
+            radiance[(size_t)kk * P.n_pixels + r] = make_float4(result.x, result.y, result.z, 0.0f);
         } else {
             cont = true;
             // the colour is +0 until a path ends in every scene the reference can describe; it only takes memory
             // traffic when it is not (non-finite throughput)
             bool has_color = (__float_as_uint(ps.color.x) | __float_as_uint(ps.color.y) | __float_as_uint(ps.color.z)) != 0u;
             QP(pool, 0, slot) = make_float4(no.x, no.y, no.z, q0.w);
-            QP(pool, 1, slot) = make_float4(nd.x, nd.y, nd.z, __uint_as_float((uint32_t)ps.depth | (has_color ? DEPTH_HAS_COLOR : 0u)));
+            QP(pool, 1, slot) = make_float4(nd.x, nd.y, nd.z, __uint_as_float((uint32_t)ps.depth | (kk << DEPTH_COLUMN_SHIFT) | (has_color ? DEPTH_HAS_COLOR : 0u)));
             QP(pool, 2, slot) = make_float4(ps.acc.x, ps.acc.y, ps.acc.z, q2.w);
             if (has_color) QP(pool, 4, slot) = make_float4(ps.color.x, ps.color.y, ps.color.z, 0.0f);
         }
