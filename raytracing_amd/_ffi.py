@@ -89,6 +89,12 @@ class rtStats(C.Structure):
 
 
 # every symbol include/rt_amd.h declares: name -> (restype, argtypes)
+class rtLayout(C.Structure):
+    _fields_ = [("nodes_per_layout", C.c_uint32), ("n_prims", C.c_uint32), ("surface_root", C.c_uint32),
+                ("surface_size", C.c_uint32), ("medium_root", C.c_uint32), ("medium_size", C.c_uint32),
+                ("nested", C.c_uint32), ("node_scale", C.c_float)]
+
+
 SYMBOLS = {
     "rt_abi_version": (C.c_int, []),
     "rt_last_error": (C.c_char_p, []),
@@ -105,6 +111,8 @@ SYMBOLS = {
                                 c_f32p, c_f32p, c_f32p, c_u8p]),
     "rt_trace_paths": (C.c_int, [C.c_void_p, C.POINTER(rtCamera), c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int,
                                  C.c_uint64, c_i32p, C.c_int, c_f32p]),
+    "rt_scene_layout": (C.c_int, [C.POINTER(rtSceneDesc), C.POINTER(rtLayout), C.POINTER(C.c_uint32), C.c_size_t,
+                                  c_i32p, C.c_size_t]),
     "rt_bvh_build": (C.c_int, [C.c_int, c_f32p, c_i32p, c_f32p, c_i32p, c_i32p, c_u8p]),
     "rt_bvh_build_meshes": (C.c_int, [C.c_int, c_i32p, C.POINTER(c_f32p), c_i32p, C.POINTER(c_i32p),
                                       C.POINTER(c_i32p), c_i32p, c_f32p, c_i32p, c_i32p, c_u8p]),

@@ -186,6 +186,23 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     return RT_OK;
 }
 
+int rt_scene_layout(const rtSceneDesc* desc, rtLayout* info, uint32_t* nodes, size_t node_capacity, int32_t* prim_top,
+                    size_t prim_capacity) {
+    if (!desc || !info) return rt_fail(RT_EINVAL, "rt_scene_layout: null argument");
+    HostScene H;
+    int st = rt_flatten_scene(desc, &H);
+    if (st != RT_OK) return st;
+    info->nodes_per_layout = H.nodes_per_layout;
+    info->n_prims = (uint32_t)(H.prims.size() / 3);
+    info->surface_root = H.surface_root; info->surface_size = H.surface_size;
+    info->medium_root = H.medium_root; info->medium_size = H.medium_size;
+    info->nested = H.nested ? 1u : 0u;
+    info->node_scale = H.node_scale;
+    if (nodes && node_capacity >= H.nodes.size()) std::memcpy(nodes, H.nodes.data(), H.nodes.size() * sizeof(uint4));
+    if (prim_top && prim_capacity >= H.prim_top.size()) std::memcpy(prim_top, H.prim_top.data(), H.prim_top.size() * sizeof(int32_t));
+    return RT_OK;
+}
+
 int rt_scene_destroy(rtScene* s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->device);

@@ -1,0 +1,178 @@
+"""The device acceleration structure (own SAH trees, eight ray-octant layouts, 16-byte half-precision nodes) checked on
+the host through rt_scene_layout: structure, coverage of the primitives, box enclosure, and that the stackless walk
+visits every primitive whose reference bounding box (src/*.jl bounding_box) the ray passes -- the walk may only cull
+what the reference's exact slab test (src/bounding_box.jl:20-67) culls too.  No GPU needed."""
+import numpy as np
+import pytest
+
+import raytracing_amd as rt
+from raytracing_amd import hittables as H
+from raytracing_amd.render import scene_layout
+
+LEAF = 0x80000000
+PRIM_MASK = 0x1FFFFFFF
+SCENES = ["cornell_box", "cornell_smoke_box", "cover1", "cu_cover2", "cover2", "teapot"]
+
+
+def boxes_of(nodes):
+    """(..., 6) float32 {min.xyz, max.xyz} of the stored half-precision boxes"""
+    h = nodes[..., :3].copy().view(np.float16).astype(np.float32)  # (.., 6): lo.x lo.y lo.z hi.x hi.y hi.z
+    return h
+
+
+def subtree_end(link, i):
+    return i + 1 if link[i] & LEAF else int(link[i])
+
+
+@pytest.fixture(scope="module")
+def layouts():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            world, kw = rt.get_scene(name, spp=1)
+            cache[name] = (world, kw) + scene_layout(world)
+        return cache[name]
+    return get
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_structure_and_coverage(name, layouts):
+    world, kw, info, nodes, prim_top = layouts(name)
+    N = info.nodes_per_layout
+    assert nodes.shape == (8, N, 4) and N > 0 and info.n_prims == len(prim_top)
+    scale = info.node_scale
+    assert scale > 0 and np.log2(scale) == np.round(np.log2(scale))          # a power of two
+    ref = None
+    for o in range(8):
+        link = nodes[o, :, 3].astype(np.int64)
+        box = boxes_of(nodes[o])
+        base = o * N
+        # every primitive is the leaf of exactly one node of the layout
+        leaves = link[(link & LEAF) != 0]
+        prims = (leaves & PRIM_MASK) - 1
+        assert np.array_equal(np.sort(prims), np.arange(info.n_prims))
+        # skip links stay inside the layout and point forward
+        inter = np.nonzero((link & LEAF) == 0)[0]
+        assert np.all(link[inter] > inter + base) and np.all(link[inter] <= base + N)
+        # pre-order consistency and enclosure of the two main trees: an interior node is followed by its first child,
+        # whose subtree ends where the second child starts, whose subtree ends at the node's skip link
+        rel = np.where((link & LEAF) != 0, link, link - base)
+        for root, size in ((info.surface_root, info.surface_size), (info.medium_root, info.medium_size)):
+            if size == 0:
+                continue
+            stack = [root]
+            seen = 0
+            while stack:
+                i = stack.pop()
+                seen += 1
+                if rel[i] & LEAF:
+                    continue
+                c1 = i + 1
+                c2 = subtree_end(rel, c1)
+                assert subtree_end(rel, c2) == rel[i]
+                for c in (c1, c2):
+                    assert np.all(box[c, :3] >= box[i, :3]) and np.all(box[c, 3:] <= box[i, 3:])
+                stack += [c1, c2]
+            assert seen == size and subtree_end(rel, root) == root + size
+        # the eight layouts hold the same nodes (boxes, leaf words), only in different orders
+        key = np.concatenate([nodes[o, :, :3], np.where((link & LEAF) != 0, link, 0).astype(np.uint32)[:, None]], axis=1)
+        key = key[np.lexsort(key.T[::-1])]
+        if ref is None:
+            ref = key
+        else:
+            assert np.array_equal(ref, key)
+    # layouts of opposite octants visit the children of the root in opposite order
+    if info.surface_size > 1:
+        r = info.surface_root
+        rel0 = nodes[0, :, 3].astype(np.int64)
+        rel7 = np.where((nodes[7, :, 3] & LEAF) != 0, nodes[7, :, 3].astype(np.int64), nodes[7, :, 3].astype(np.int64) - 7 * N)
+        a, b = boxes_of(nodes[0]), boxes_of(nodes[7])
+        assert np.array_equal(a[r + 1], b[subtree_end(rel7, r + 1)])
+        assert np.array_equal(a[subtree_end(rel0, r + 1)], b[r + 1])
+
+
+def walk(nodes, info, octant, root, size, o, d, t_min=0.001):
+    """the stackless walk of rt_kernels.hip for one ray, in float32 like the kernel (exact division instead of the
+    hardware reciprocal); returns the list of leaf words visited with the box passed"""
+    N = info.nodes_per_layout
+    F = np.float32
+    scale = F(info.node_scale)
+    os_ = (o * scale).astype(F)
+    with np.errstate(divide="ignore"):
+        inv = (F(1) / d).astype(F) * (F(1) / scale)
+    link = nodes[octant, :, 3]
+    box = boxes_of(nodes[octant])
+    node = octant * N + root
+    end = node + size
+    out = []
+    while node != end:
+        i = node - octant * N
+        with np.errstate(invalid="ignore"):
+            t0 = (box[i, :3] - os_) * inv
+            t1 = (box[i, 3:] - os_) * inv
+        tnear = max(np.fmax.reduce(np.fmin(t0, t1)), F(t_min))
+        tfar = np.fmin.reduce(np.fmax(t0, t1))
+        with np.errstate(invalid="ignore"):
+            tfar = tfar + abs(tfar) * F(4.8e-7)
+        hit = tnear <= tfar
+        w = int(link[i])
+        if w & LEAF:
+            if hit:
+                out.append(w & ~LEAF)
+            node += 1
+        else:
+            node = node + 1 if hit else w
+    return out
+
+
+def slab_exact(bmin, bmax, o, d, t_min=0.001):
+    """src/bounding_box.jl:20-67 in float64"""
+    tmin, tmax = float(t_min), np.inf
+    for a in range(3):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = np.float64(1.0) / np.float64(d[a])
+            t0 = (np.float64(bmin[a]) - np.float64(o[a])) * inv
+            t1 = (np.float64(bmax[a]) - np.float64(o[a])) * inv
+        if inv < 0.0:
+            t0, t1 = t1, t0
+        tmin = t0 if t0 > tmin else tmin
+        tmax = t1 if t1 < tmax else tmax
+        if tmax <= tmin:
+            return False
+    return True
+
+
+@pytest.mark.parametrize("name", ["cornell_smoke_box", "cu_cover2", "cover1"])
+def test_walk_never_culls_what_the_reference_visits(name, layouts):
+    world, kw, info, nodes, prim_top = layouts(name)
+    rng = np.random.default_rng(7)
+    cam = kw["camera"]
+    boxes = [H.bounding_box(obj) for obj in world]
+    is_medium = np.array([isinstance(obj, H.ConstantMedium) for obj in world])
+    lo = np.array([b.min for b in boxes], np.float32)
+    hi = np.array([b.max for b in boxes], np.float32)
+    finite = np.isfinite(lo).all(axis=1) & np.isfinite(hi).all(axis=1)
+    centre = 0.5 * (lo[finite].min(axis=0) + hi[finite].max(axis=0))
+    extent = (hi[finite].max(axis=0) - lo[finite].min(axis=0)).max()
+    n_rays = 48
+    for k in range(n_rays):
+        if k % 2 == 0:   # from the camera towards the scene
+            o = np.asarray(cam.origin, np.float32)
+            target = centre + rng.uniform(-0.5, 0.5, 3) * extent
+        else:            # between two points inside the scene bounds (secondary rays), incl. axis-parallel ones
+            o = (centre + rng.uniform(-0.5, 0.5, 3) * extent).astype(np.float32)
+            target = centre + rng.uniform(-0.5, 0.5, 3) * extent
+            if k % 8 == 1:
+                target[rng.integers(3)] = o[rng.integers(3)]
+        d = (target - o).astype(np.float32)
+        if k % 16 == 3:
+            d[rng.integers(3)] = 0.0
+        octant = int(d[0] < 0) | (int(d[1] < 0) << 1) | (int(d[2] < 0) << 2)
+        visited = set()
+        for root, size in ((info.surface_root, info.surface_size), (info.medium_root, info.medium_size)):
+            if size:
+                visited |= {prim_top[(w & PRIM_MASK) - 1] for w in walk(nodes, info, octant, root, size, o, d)}
+        for idx in range(len(world)):
+            if slab_exact(lo[idx], hi[idx], o, d):
+                assert idx in visited, (name, k, idx, type(world[idx]).__name__, bool(is_medium[idx]))
