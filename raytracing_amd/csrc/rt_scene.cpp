@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -129,11 +130,16 @@ struct Builder {
     bool valid_obj(int oi) { return oi >= 0 && oi < D.n_objects; }
 
     // number of tie-break ranks an object occupies
-    uint32_t flat_count(int oi) {
-        if (!valid_obj(oi)) return 1;
+    uint32_t flat_count(int oi, int depth = 0) {
+        if (!valid_obj(oi) || depth > 4) return 1;
         const rtObject* o = &D.objects[oi];
         if (o->kind == RT_TRANSFORM && valid_obj(o->child)) o = &D.objects[o->child];
-        if (o->kind == RT_BVH && o->aux >= 0 && o->aux < D.n_groups) return (uint32_t)D.groups[o->aux].n_objects;
+        if (o->kind == RT_BVH && o->aux >= 0 && o->aux < D.n_groups) {
+            const rtBvh& G = D.groups[o->aux];
+            uint32_t acc = 0;
+            for (int k = 0; k < G.n_objects && G.objects; ++k) acc += flat_count(G.objects[k], depth + 1);
+            return acc;
+        }
         if (o->kind == RT_MESH && o->aux >= 0 && o->aux < D.n_meshes) return (uint32_t)D.meshes[o->aux].n_triangles;
         return 1;
     }
@@ -216,6 +222,61 @@ struct Builder {
         items.push_back(it);
     }
 
+    // Bounds of primitive `prim` for the device tree: never larger than the box the reference walks for it (`leaf_box`,
+    // so nothing is found that the reference culls), but tight around spheres and rectangles where the reference's box
+    // is loose (the box of a rotated Transform is the box of eight corners).  The padding covers the rounding of the primitive tests, which accept points slightly outside the exact
+    // shape (src/sphere.jl:46-63 loses about |o - c|^2 / r^2 ulps of the discriminant to cancellation).
+    void tight_box(uint32_t prim, const float* leaf_box, float* out) {
+        std::memcpy(out, leaf_box, 6 * sizeof(float));
+        const uint4 h = H.prims[3 * (size_t)prim], a = H.prims[3 * (size_t)prim + 1];
+        const uint32_t kind = h.x & 15u, field = h.x >> 8;
+        if (h.x & DP_MEDIUM_FLAG) return;
+        const float g[5] = {bitsf(h.w), bitsf(a.x), bitsf(a.y), bitsf(a.z), bitsf(a.w)};
+        double M[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}; // forward matrix, column-major 3x4
+        if (field) for (int k = 0; k < 12; ++k) M[k] = (double)H.xforms[24 * (size_t)(field - 1) + k];
+        auto point = [&M](double x, double y, double z, double* w) {
+            for (int i = 0; i < 3; ++i) w[i] = M[i] * x + M[3 + i] * y + M[6 + i] * z + M[9 + i];
+        };
+        double lo[3], hi[3];
+        if (kind == DP_SPHERE) {
+            double c[3];
+            point(g[0], g[1], g[2], c);
+            double r = std::fabs((double)g[3]);
+            for (int i = 0; i < 3; ++i) {
+                double e = r * std::sqrt(M[i] * M[i] + M[3 + i] * M[3 + i] + M[6 + i] * M[6 + i]);
+                e = e * 1.02 + 4e-6 * std::fabs(c[i]);
+                lo[i] = c[i] - e; hi[i] = c[i] + e;
+            }
+        } else if (kind == DP_XY_RECT || kind == DP_XZ_RECT || kind == DP_YZ_RECT) {
+            const int ka = kind == DP_XY_RECT ? 2 : (kind == DP_XZ_RECT ? 1 : 0); // constant axis
+            const int aa = kind == DP_YZ_RECT ? 1 : 0, ba = kind == DP_XY_RECT ? 1 : 2;
+            for (int i = 0; i < 3; ++i) { lo[i] = INFINITY; hi[i] = -INFINITY; }
+            for (int corner = 0; corner < 8; ++corner) {
+                double p[3], w[3];
+                p[aa] = (corner & 1) ? g[1] : g[0];
+                p[ba] = (corner & 2) ? g[3] : g[2];
+                p[ka] = (double)g[4] + ((corner & 4) ? 0.0001 : -0.0001); // the padding of src/aarect.jl:37-47
+                point(p[0], p[1], p[2], w);
+                for (int i = 0; i < 3; ++i) { lo[i] = std::min(lo[i], w[i]); hi[i] = std::max(hi[i], w[i]); }
+            }
+            double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+            for (int i = 0; i < 3; ++i) {
+                double e = 1e-4 * ext + 4e-6 * std::max(std::fabs(lo[i]), std::fabs(hi[i]));
+                lo[i] -= e; hi[i] += e;
+            }
+        } else {
+            return;
+        }
+        float box[6];
+        for (int i = 0; i < 3; ++i) {
+            if (!std::isfinite(lo[i]) || !std::isfinite(hi[i])) return;
+            box[i] = std::max(std::nextafter((float)lo[i], -INFINITY), leaf_box[i]);
+            box[3 + i] = std::min(std::nextafter((float)hi[i], INFINITY), leaf_box[3 + i]);
+            if (!(box[i] <= box[3 + i])) return; // NaN or empty: keep the reference's box
+        }
+        std::memcpy(out, box, sizeof(box));
+    }
+
     // generic tree (src/BVH.jl)
     bool collect_generic(const rtBvh& T, int id, int depth, std::vector<AccelItem>& items, uint32_t rank_base,
                          const std::vector<uint32_t>* rank_offset, bool nested, int nested_top) {
@@ -226,12 +287,14 @@ struct Builder {
             int oi = T.objects[l - 1];
             uint32_t rank = rank_base + (rank_offset ? (*rank_offset)[(size_t)(l - 1)] : (uint32_t)(l - 1));
             int top = nested ? nested_top : (valid_obj(oi) ? top_pos[(size_t)oi] : -1);
+            const float* leaf_box = T.node_bounds + 6 * (size_t)(id - 1);
             uint32_t prim;
             if (!make_prim(oi, rank, top, nested ? oi : 0, nested, prim)) return false;
             uint32_t head = H.prims[3 * (size_t)prim].x;
             bool instance = (head & 15u) == DP_INSTANCE;
-            add_item(items, T.node_bounds + 6 * (size_t)(id - 1), prim,
-                     instance ? RT_LEAF_INSTANCE : ((head >> 8) ? RT_LEAF_XFORM : 0u));
+            float box[6];
+            tight_box(prim, leaf_box, box);
+            add_item(items, box, prim, instance ? RT_LEAF_INSTANCE : ((head >> 8) ? RT_LEAF_XFORM : 0u));
             return true;
         }
         return collect_generic(T, T.node_left[id - 1], depth + 1, items, rank_base, rank_offset, nested, nested_top) &&
@@ -251,11 +314,18 @@ struct Builder {
         if (group_root[(size_t)gi] >= 0) { root = group_root[(size_t)gi]; return true; }
         const rtBvh& T = D.groups[gi];
         if (T.kind != 0) return fail(RT_EUNSUPPORTED, "nested tree of meshes is not supported");
-        if (T.n_objects <= 0 || T.n_nodes <= 0) return fail(RT_EINVAL, "empty nested tree");
+        if (T.n_objects <= 0 || T.n_nodes <= 0 || !T.objects || !T.node_bounds || !T.node_left || !T.node_right || !T.node_leaf)
+            return fail(RT_EINVAL, "empty or incomplete nested tree");
         std::vector<AccelItem> items;
         size_t saved = visited;
         visited = 0;
-        bool ok = collect_generic(T, 1, 0, items, 0u, nullptr, true, top);
+        std::vector<uint32_t> offsets;
+        uint32_t acc = 0;
+        for (int k = 0; k < T.n_objects; ++k) {
+            offsets.push_back(acc);
+            acc += flat_count(T.objects[k]);
+        }
+        bool ok = collect_generic(T, 1, 0, items, 0u, &offsets, true, top);
         visited = saved;
         if (!ok) return false;
         size_t start = sub_nodes[0].size();
