@@ -16,7 +16,9 @@ struct RtCameraDev { // same field order as rtCamera (src/camera.jl:3-14)
 #define RT_DISP_UNIT 256u  // consecutive paths dealt to one dispenser
 #define RT_DISP_BASE 64u   // first dispenser word in the sync array
 #define RT_DISP_STRIDE 32u // words between dispensers (128 bytes)
-#define RT_SYNC_WORDS (RT_DISP_BASE + RT_DISP_MAX * RT_DISP_STRIDE)
+#define RT_SLOT_DISP 64u   // slot dispensers of the extend kernel (each hands out one contiguous share of the slots)
+#define RT_SLOT_DISP_BASE (RT_DISP_BASE + RT_DISP_MAX * RT_DISP_STRIDE)
+#define RT_SYNC_WORDS (RT_SLOT_DISP_BASE + RT_SLOT_DISP * RT_DISP_STRIDE)
 
 struct PathPool { // per-slot path state, five float4 planes of n_slots entries each (see rt_kernels.hip)
     float4* q;

@@ -997,6 +997,9 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
     const float t_min = 0.001f;
     Counters cnt = {0, 0, 0, 0, 0, 0};
     uint32_t cur = 0, cur_end = 0; // wave-uniform cursor into the chunk of slots this wave owns
+    const uint32_t slot_share = ((pool.n_slots + RT_SLOT_DISP - 1u) / RT_SLOT_DISP + EXTEND_CHUNK - 1u) / EXTEND_CHUNK * EXTEND_CHUNK;
+    const uint32_t disp_first = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % RT_SLOT_DISP;
+    uint32_t disp_tries = 0;
     bool exhausted = false;
     bool busy = false;
     uint32_t slot = 0;
@@ -1037,17 +1040,37 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
             if (!exhausted) {
                 unsigned long long m = __ballot(!busy);
                 if (cur >= cur_end) { // take the next chunk of slots
-                    uint32_t base = 0;
-                    if (lane == 0u) base = atomicAdd(head, EXTEND_CHUNK);
+                    // RT_SLOT_DISP counters on separate cache lines, each handing out one contiguous share of the slots
+                    // (a single counter serialises thousands of atomics per launch); a wave starts at "its" counter and
+                    // moves on to the next few when that share is used up
+                    uint32_t base = 0xFFFFFFFFu, limit = 0u;
+                    if (lane == 0u) {
+                        for (; disp_tries < 4u; ++disp_tries) {
+                            const uint32_t c = (disp_first + disp_tries) % RT_SLOT_DISP;
+                            const uint32_t lo = c * slot_share;
+                            if (lo >= pool.n_slots) continue;
+                            const uint32_t size = min(slot_share, pool.n_slots - lo);
+                            uint32_t* ctr = head + RT_SLOT_DISP_BASE + c * RT_DISP_STRIDE;
+                            if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= size) continue;
+                            const uint32_t v = atomicAdd(ctr, EXTEND_CHUNK);
+                            if (v >= size) continue;
+                            base = lo + v;
+                            limit = lo + size;
+                            break;
+                        }
+                    }
                     base = (uint32_t)__shfl((int)base, 0);
-                    if (base >= pool.n_slots) { exhausted = true; cur = cur_end = 0; }
-                    else { cur = base; cur_end = min(base + EXTEND_CHUNK, pool.n_slots); }
+                    limit = (uint32_t)__shfl((int)limit, 0);
+                    disp_tries = (uint32_t)__shfl((int)disp_tries, 0);
+                    if (base == 0xFFFFFFFFu) { exhausted = true; cur = cur_end = 0; }
+                    else { cur = base; cur_end = min(base + EXTEND_CHUNK, limit); }
                 }
                 if (!exhausted) {
                     if (!busy) {
                         uint32_t sidx = cur + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                         if (sidx < cur_end) {
                             float4 p1 = QP(pool, 1, sidx), p0 = QP(pool, 0, sidx);
+                            asm volatile("" : "+v"(p0.x), "+v"(p1.x)); // both loads in flight before the depth is looked at
                             if ((__float_as_uint(p1.w) & DEPTH_MASK) != 0u) {
                                 slot = sidx;
                                 busy = true;
@@ -1145,7 +1168,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
 }
 
 #define SHADE_BLOCK 256
-// sync[0]: slot dispenser of rt_extend_kernel (reset here), sync[DISP_BASE + c * DISP_STRIDE]: path dispenser c,
+// sync[RT_SLOT_DISP_BASE + c * DISP_STRIDE]: slot dispenser c of rt_extend_kernel (reset here), sync[DISP_BASE + c * DISP_STRIDE]: path dispenser c,
 // active: set to 1 if any slot holds a ray after this bounce
 template <bool TEXTURED>
 __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCameraDev cam, const float* __restrict__ pattern,
@@ -1159,7 +1182,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
     const uint32_t base = blockIdx.x * SHADE_BLOCK;
     if (t < 8u) { hist[t] = 0u; }
     if (t == 0u) { block_alive = 0u; block_need = 0u; }
-    if (blockIdx.x == 0 && t == 0u) sync[0] = 0u; // re-arm the slot dispenser of the next rt_extend_kernel
+    if (blockIdx.x == 0 && t < RT_SLOT_DISP) sync[RT_SLOT_DISP_BASE + t * RT_DISP_STRIDE] = 0u; // re-arm the slot dispensers
     __syncthreads();
     // Phase 1, thread t on slot base + t: the constant media of the scene against the slot's ray (every lane of the
     // wave has a ray, so the medium test runs converged), then the material type of the final hit; 7 = nothing to shade
