@@ -219,6 +219,15 @@ int rt_bvh_build_meshes(int n_meshes, const int32_t* n_vertices, const float* co
                         uint8_t* node_leaf);
 
 
+/* The step after the path, which the reference leaves to Images.jl: `save(path, clamp01.(img))` (README.md:50-67).
+ * rt_finalize_rgb8 = rt_finalize followed by clamp to [0, 1] (NaN -> 0) and N0f8 quantisation (round to nearest even of
+ * x * 255) on the device; d_rgb8 is H x W x 3 bytes, row-major, row 0 = top (the order PNG wants).
+ * rt_image_to_rgb8 does the same on the host for an image in rt_render's layout. */
+int rt_finalize_rgb8(rtScene* scene, const float* d_accum, int n_total, int width, int height, uint8_t* d_rgb8, void* stream);
+int rt_image_to_rgb8(const float* img, int width, int height, uint8_t* rgb8);
+int rt_write_png(const char* path, const uint8_t* rgb8, int width, int height); /* 8-bit RGB, deflate */
+int rt_write_ppm(const char* path, const uint8_t* rgb8, int width, int height); /* binary P6 */
+
 /* Test hook without a counterpart in the reference: the acceleration structure the library builds for a scene
  * (its own SAH trees in eight ray-octant layouts, see raytracing_amd/csrc/rt_device.h), computed on the host without
  * a GPU, so that its invariants (every primitive once per layout, links in range, boxes that enclose the reference's

@@ -111,6 +111,10 @@ SYMBOLS = {
                                 c_f32p, c_f32p, c_f32p, c_u8p]),
     "rt_trace_paths": (C.c_int, [C.c_void_p, C.POINTER(rtCamera), c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int,
                                  C.c_uint64, c_i32p, C.c_int, c_f32p]),
+    "rt_finalize_rgb8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "rt_image_to_rgb8": (C.c_int, [c_f32p, C.c_int, C.c_int, c_u8p]),
+    "rt_write_png": (C.c_int, [C.c_char_p, c_u8p, C.c_int, C.c_int]),
+    "rt_write_ppm": (C.c_int, [C.c_char_p, c_u8p, C.c_int, C.c_int]),
     "rt_scene_layout": (C.c_int, [C.POINTER(rtSceneDesc), C.POINTER(rtLayout), C.POINTER(C.c_uint32), C.c_size_t,
                                   c_i32p, C.c_size_t]),
     "rt_bvh_build": (C.c_int, [C.c_int, c_f32p, c_i32p, c_f32p, c_i32p, c_i32p, c_u8p]),

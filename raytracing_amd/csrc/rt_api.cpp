@@ -336,6 +336,16 @@ int rt_finalize(rtScene* s, const float* d_accum, int n_total, int width, int he
     return RT_OK;
 }
 
+int rt_finalize_rgb8(rtScene* s, const float* d_accum, int n_total, int width, int height, uint8_t* d_rgb8, void* stream_) {
+    if (!s || !d_accum || !d_rgb8) return rt_fail(RT_EINVAL, "rt_finalize_rgb8: null argument");
+    if (n_total <= 0 || width < 1 || height < 1) return rt_fail(RT_EINVAL, "rt_finalize_rgb8: bad size");
+    HIP_TRY(hipSetDevice(s->device));
+    float inv_n = (float)(1.0 / (double)n_total);
+    rt_launch_finalize_rgb8(d_accum, inv_n, width, height, d_rgb8, (hipStream_t)stream_);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
 int rt_get_counters(rtScene* s, rtStats* stats) {
     if (!s || !stats) return rt_fail(RT_EINVAL, "rt_get_counters: null argument");
     HIP_TRY(hipSetDevice(s->device));

@@ -45,14 +45,15 @@ struct RtRenderParams {
 extern "C" {
 void rt_launch_init(const RtCameraDev* cam, const float* d_pattern, const RtRenderParams* P, const PathPool* pool,
                     hipStream_t stream);
-// one bounce of every slot: extend (closest hits) then shade (scatter / next path).  d_sync[0] is the slot dispenser
-// (zero before the first bounce), d_sync[1] the next unstarted path; *d_active receives the number of slots that still
-// hold a ray after the bounce.
+// one bounce of every slot: extend (closest hits) then shade (scatter / next path).  d_sync holds the slot dispensers
+// (zero before the first bounce) and the path dispensers; *d_active is set to 1 if any slot still holds a ray after the
+// bounce.
 void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, const float* d_pattern, const RtRenderParams* P,
                       const PathPool* pool, uint32_t extend_blocks, float4* d_radiance, uint32_t* d_sync, uint32_t* d_active,
                       unsigned long long* d_counters, bool count, hipEvent_t* timing, hipStream_t stream);
 void rt_launch_sum(const RtRenderParams* P, const float4* d_radiance, float* d_accum, int first_batch, hipStream_t stream);
 void rt_launch_finalize(const float* d_accum, float inv_n, size_t image_floats, float* d_out, hipStream_t stream);
+void rt_launch_finalize_rgb8(const float* d_accum, float inv_n, int width, int height, uint8_t* d_out, hipStream_t stream);
 void rt_launch_trace_rays(const DevScene* S, const float* d_rays, int n, float t_min, float t_max, uint32_t seed32,
                           int32_t* prim_id, int32_t* sub_id, float* t, float* normal, float* uv, uint8_t* front,
                           hipStream_t stream);

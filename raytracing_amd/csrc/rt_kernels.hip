@@ -1334,6 +1334,21 @@ __global__ void __launch_bounds__(256) rt_finalize_kernel(const float* __restric
     out[i] = sqrtf(accum[i] * inv_n);
 }
 
+// rt_finalize_kernel + clamp01 + N0f8 (round to nearest even of x * 255); out is H x W x 3 bytes, row-major, row 0 = top
+__global__ void __launch_bounds__(256) rt_finalize_rgb8_kernel(const float* __restrict__ accum, float inv_n, int width, int height,
+                                                               uint8_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)width * (size_t)height) return;
+    int y = (int)(i / (size_t)width), x = (int)(i - (size_t)y * (size_t)width);
+    const float* a = accum + ((size_t)x * (size_t)height + (size_t)y) * 3u;
+    for (int c = 0; c < 3; ++c) {
+        float v = sqrtf(a[c] * inv_n);
+        if (!(v == v)) v = 0.0f;
+        v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        out[i * 3u + (size_t)c] = (uint8_t)__builtin_rintf(v * 255.0f);
+    }
+}
+
 __global__ void __launch_bounds__(256) rt_trace_rays_kernel(DevScene S, const float* __restrict__ rays, int n, float t_min,
                                                             float t_max, uint32_t seed32, int32_t* prim_id,
                                                             int32_t* sub_id, float* t_out, float* normal, float* uv,
@@ -1443,6 +1458,10 @@ extern "C" void rt_launch_sum(const RtRenderParams* P, const float4* d_radiance,
 extern "C" void rt_launch_finalize(const float* d_accum, float inv_n, size_t image_floats, float* d_out, hipStream_t stream) {
     uint32_t blocks = (uint32_t)((image_floats + 255) / 256);
     hipLaunchKernelGGL(rt_finalize_kernel, dim3(blocks), dim3(256), 0, stream, d_accum, inv_n, image_floats, d_out);
+}
+extern "C" void rt_launch_finalize_rgb8(const float* d_accum, float inv_n, int width, int height, uint8_t* d_out, hipStream_t stream) {
+    uint32_t blocks = (uint32_t)(((size_t)width * (size_t)height + 255) / 256);
+    hipLaunchKernelGGL(rt_finalize_rgb8_kernel, dim3(blocks), dim3(256), 0, stream, d_accum, inv_n, width, height, d_out);
 }
 extern "C" void rt_launch_trace_rays(const DevScene* S, const float* d_rays, int n, float t_min, float t_max, uint32_t seed32,
                                      int32_t* prim_id, int32_t* sub_id, float* t, float* normal, float* uv, uint8_t* front,

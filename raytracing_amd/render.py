@@ -98,6 +98,11 @@ class DeviceScene:
         ffi.check(ffi.lib().rt_finalize(self.handle, C.c_void_p(d_accum), n_total, width, height,
                                         C.c_void_p(d_out), C.c_void_p(stream or 0)))
 
+    def finalize_rgb8(self, d_accum, n_total, width, height, d_rgb8, stream=None):
+        """rt_finalize + clamp01 + 8-bit quantisation on the device; d_rgb8 receives height x width x 3 bytes."""
+        ffi.check(ffi.lib().rt_finalize_rgb8(self.handle, C.c_void_p(d_accum), n_total, width, height,
+                                             C.c_void_p(d_rgb8), C.c_void_p(stream or 0)))
+
     def counters(self):
         st = ffi.rtStats()
         ffi.check(ffi.lib().rt_get_counters(self.handle, C.byref(st)))
@@ -156,3 +161,27 @@ def render(world, material=None, *, width=None, height=None, camera=None, backgr
     finally:
         scene.close()
     return img
+
+
+def clamp01(img):
+    """clamp01.(img) with NaN -> 0 (clamp01nan), as the reference's README asks before saving (README.md:56-63)"""
+    a = np.asarray(img, dtype=F)
+    return np.clip(np.where(np.isnan(a), F(0), a), F(0), F(1))
+
+
+def to_rgb8(img):
+    """(height, width, 3) float image -> uint8 the way Images.jl stores N0f8: round-to-nearest-even of clamp01(x) * 255"""
+    a = np.ascontiguousarray(np.asarray(img, dtype=F).transpose(1, 0, 2))  # rt_render's memory order [col][row][rgb]
+    h, w = img.shape[0], img.shape[1]
+    out = np.zeros((h, w, 3), dtype=np.uint8)
+    ffi.check(ffi.lib().rt_image_to_rgb8(ffi.fptr(a), w, h, ffi.bptr(out)))
+    return out
+
+
+def save(path, img):
+    """save(path, clamp01.(img)) (README.md:50-67): PNG (or binary PPM for a .ppm path), 8 bits per channel"""
+    rgb = to_rgb8(img)
+    h, w = rgb.shape[0], rgb.shape[1]
+    fn = ffi.lib().rt_write_ppm if str(path).lower().endswith(".ppm") else ffi.lib().rt_write_png
+    ffi.check(fn(str(path).encode(), ffi.bptr(rgb), w, h))
+    return path

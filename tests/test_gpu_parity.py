@@ -173,6 +173,27 @@ def test_sample_sharding_sums_to_the_full_frame(scenes):
         np.testing.assert_allclose(img, full, rtol=2e-6, atol=1e-7)
 
 
+def test_device_output_stage_matches_host_quantisation(scenes):
+    """rt_finalize_rgb8 (clamp01 + N0f8 on the device) == rt_finalize followed by the host quantisation"""
+    import torch
+    world, kw, dev, ref = scenes("cornell_box")                       # its light (15) is far outside [0, 1]
+    cam, bg = kw["camera"], kw["background"]
+    pat = rt.Halton_sequence32(6)
+    W, H = 50, 38
+    stream = torch.cuda.current_stream().cuda_stream
+    acc = torch.zeros(3 * W * H, dtype=torch.float32, device="cuda")
+    dev.accumulate(cam, pat, bg, W, H, acc.data_ptr(), stream=stream)
+    out = torch.zeros_like(acc)
+    rgb = torch.zeros(H * W * 3, dtype=torch.uint8, device="cuda")
+    dev.finalize(acc.data_ptr(), 6, W, H, out.data_ptr(), stream=stream)
+    dev.finalize_rgb8(acc.data_ptr(), 6, W, H, rgb.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    img = out.cpu().numpy().reshape(W, H, 3).transpose(1, 0, 2)
+    got = rgb.cpu().numpy().reshape(H, W, 3)
+    np.testing.assert_array_equal(got, rt.to_rgb8(img))
+    assert got.max() == 255 and img.max() > 1.0
+
+
 def test_full_size_cu_cover2_against_oracle_and_properties(scenes):
     """BASELINE configuration at full resolution (800x800): a few pattern columns against the oracle bit for bit, and
     size-independent properties at more columns: run-to-run determinism and column-additivity."""
