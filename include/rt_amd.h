@@ -228,6 +228,19 @@ int rt_image_to_rgb8(const float* img, int width, int height, uint8_t* rgb8);
 int rt_write_png(const char* path, const uint8_t* rgb8, int width, int height); /* 8-bit RGB, deflate */
 int rt_write_ppm(const char* path, const uint8_t* rgb8, int width, int height); /* binary P6 */
 
+/* The step before the path for render(filename, material) (main.jl:53-81): a Wavefront OBJ file as the vertex and
+ * index arrays of an rtMesh (vertices: 8 floats each = position, normal, u, v; indices: 4 int32 per triangle = three
+ * 0-based vertex numbers + material slot 0).  One vertex per distinct v/vt/vn triple in order of first appearance,
+ * polygons fan-triangulated, missing normals (0,0,0), missing texture coordinates (-1,-1) (main.jl:62-67).  The
+ * arrays are allocated by the library; release them with rt_obj_free. */
+typedef struct rtObjMesh {
+    int32_t n_vertices, n_triangles;
+    float* vertices;
+    int32_t* indices;
+} rtObjMesh;
+int rt_obj_load(const char* path, rtObjMesh* out);
+void rt_obj_free(rtObjMesh* mesh);
+
 /* Test hook without a counterpart in the reference: the acceleration structure the library builds for a scene
  * (its own SAH trees in eight ray-octant layouts, see raytracing_amd/csrc/rt_device.h), computed on the host without
  * a GPU, so that its invariants (every primitive once per layout, links in range, boxes that enclose the reference's

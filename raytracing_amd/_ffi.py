@@ -95,6 +95,10 @@ class rtLayout(C.Structure):
                 ("nested", C.c_uint32), ("node_scale", C.c_float)]
 
 
+class rtObjMesh(C.Structure):
+    _fields_ = [("n_vertices", C.c_int32), ("n_triangles", C.c_int32), ("vertices", c_f32p), ("indices", c_i32p)]
+
+
 SYMBOLS = {
     "rt_abi_version": (C.c_int, []),
     "rt_last_error": (C.c_char_p, []),
@@ -115,6 +119,8 @@ SYMBOLS = {
     "rt_image_to_rgb8": (C.c_int, [c_f32p, C.c_int, C.c_int, c_u8p]),
     "rt_write_png": (C.c_int, [C.c_char_p, c_u8p, C.c_int, C.c_int]),
     "rt_write_ppm": (C.c_int, [C.c_char_p, c_u8p, C.c_int, C.c_int]),
+    "rt_obj_load": (C.c_int, [C.c_char_p, C.POINTER(rtObjMesh)]),
+    "rt_obj_free": (None, [C.POINTER(rtObjMesh)]),
     "rt_scene_layout": (C.c_int, [C.POINTER(rtSceneDesc), C.POINTER(rtLayout), C.POINTER(C.c_uint32), C.c_size_t,
                                   c_i32p, C.c_size_t]),
     "rt_bvh_build": (C.c_int, [C.c_int, c_f32p, c_i32p, c_f32p, c_i32p, c_i32p, c_u8p]),

@@ -12,6 +12,22 @@ F = np.float32
 
 
 def load_obj(filename):
+    """(vertices (nv, 8) float32, indices (ntri, 4) int32) through the library's loader (rt_obj_load)"""
+    import ctypes as C
+    from . import _ffi as ffi
+    mesh = ffi.rtObjMesh()
+    L = ffi.lib()
+    ffi.check(L.rt_obj_load(str(filename).encode(), C.byref(mesh)))
+    try:
+        vertices = np.ctypeslib.as_array(mesh.vertices, shape=(max(1, mesh.n_vertices), 8))[:mesh.n_vertices].copy()
+        indices = np.ctypeslib.as_array(mesh.indices, shape=(max(1, mesh.n_triangles), 4))[:mesh.n_triangles].copy()
+    finally:
+        L.rt_obj_free(C.byref(mesh))
+    return vertices.astype(F), indices.astype(np.int32)
+
+
+def load_obj_py(filename):
+    """the same loader in plain Python (kept to cross-check the native one)"""
     pos, tex, nrm = [], [], []
     verts, vert_index, tris = [], {}, []
     with open(filename) as f:
