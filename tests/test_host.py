@@ -19,7 +19,7 @@ F = np.float32
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(rt_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(rt_\w+)\s*\(", header, flags=re.M))
     assert declared == set(ffi.SYMBOLS), declared ^ set(ffi.SYMBOLS)
     lib = C.CDLL(ffi.LIB_PATH)
     for name in declared:
