@@ -849,16 +849,22 @@ __device__ __forceinline__ bool shade(const DevScene& S, f3 o, f3 d, float time,
     complete_hit<false>(S, o, d, time, best, h);
     uint4 m = S.materials[h.material];
     uint32_t type = m.x & 0xFFu;
+    // What several materials need is evaluated once for the whole wave, not once per material: the rejection loop of
+    // random_in_unit_sphere (Lambertian, Metal, Isotropic draw the same numbers from the same counters) and the texture.
+    f3 rs = mk3(0.0f, 0.0f, 0.0f);
+    if (type == 1u || type == 2u || type == 5u) rs = random_in_unit_sphere(key);
+    f3 tex = mk3(1.0f, 1.0f, 1.0f);
+    if (type != 3u) tex = texture_value<TEXTURED>(S, m.y, h.u, h.v, h.p);
     f3 att;
     f3 emitted = mk3(0.0f, 0.0f, 0.0f);
     if (type == 1u) { // Lambertian
-        nd = h.n + normalize3(random_in_unit_sphere(key));
+        nd = h.n + normalize3(rs);
         if (is_zero3(nd)) nd = h.n;
-        att = texture_value<TEXTURED>(S, m.y, h.u, h.v, h.p);
+        att = tex;
     } else if (type == 2u) { // Metal
         f3 reflected = reflect3(normalize3(d), h.n);
-        nd = reflected + __uint_as_float(m.z) * random_in_unit_sphere(key);
-        att = dot3(nd, h.n) > 0.0f ? texture_value<TEXTURED>(S, m.y, h.u, h.v, h.p) : mk3(0.0f, 0.0f, 0.0f);
+        nd = reflected + __uint_as_float(m.z) * rs;
+        att = dot3(nd, h.n) > 0.0f ? tex : mk3(0.0f, 0.0f, 0.0f);
     } else if (type == 3u) { // Dielectric
         float eta = __uint_as_float(m.w);
         float ratio = h.front ? (1.0f / eta) : eta;
@@ -870,12 +876,12 @@ __device__ __forceinline__ bool shade(const DevScene& S, f3 o, f3 d, float time,
         nd = refl ? reflect3(unit_dir, h.n) : refract3(unit_dir, h.n, ratio);
         att = mk3(1.0f, 1.0f, 1.0f);
     } else if (type == 5u) { // Isotropic
-        nd = random_in_unit_sphere(key);
-        att = texture_value<TEXTURED>(S, m.y, h.u, h.v, h.p);
+        nd = rs;
+        att = tex;
     } else { // Emissive: zero ray, zero attenuation (src/hittable.jl:72-74), emits on both faces (:77-83)
         nd = mk3(0.0f, 0.0f, 0.0f);
         att = mk3(0.0f, 0.0f, 0.0f);
-        emitted = texture_value<TEXTURED>(S, m.y, h.u, h.v, h.p);
+        emitted = tex;
     }
     ps.color = ps.color + ps.acc * emitted;
     if (is_zero3(att)) { result = ps.color; return true; }
