@@ -199,19 +199,22 @@ void accel_build(std::vector<AccelItem>& items, AccelTree& tree) {
     }
 }
 
-// float -> IEEE half, rounded toward -infinity (up = false) or +infinity (up = true); NaN gives the infinity of the
-// rounding direction, so a box with a NaN bound stays unconstrained on that side
+// float -> IEEE half strictly below (up = false) or strictly above (up = true) x; +-infinity stay; NaN gives the
+// infinity of the rounding direction, so a box with a NaN bound stays unconstrained on that side.  Strictly: a ray that
+// runs inside a face of the reference's box (direction component 0, origin exactly on the plane: 0 * Inf = NaN in the
+// slab test, which the reference's comparisons then ignore) is strictly inside the stored box and never meets that NaN.
 uint16_t accel_half(float x, bool up) {
     if (!(x == x)) return up ? 0x7C00u : 0xFC00u;
     _Float16 hf = (_Float16)x; // round to nearest even
     uint16_t h;
     std::memcpy(&h, &hf, 2);
     float back = (float)hf;
-    if (up && back < x) {        // one step toward +infinity
+    if (back == x && (h & 0x7FFFu) == 0x7C00u) return h; // infinite
+    if (up && back <= x) {        // one step toward +infinity
         if (h == 0x8000u) h = 0x0001u;
         else if (h & 0x8000u) h -= 1u;
         else h += 1u;
-    } else if (!up && back > x) { // one step toward -infinity
+    } else if (!up && back >= x) { // one step toward -infinity
         if (h == 0x0000u) h = 0x8001u;
         else if (h & 0x8000u) h += 1u;
         else h -= 1u;

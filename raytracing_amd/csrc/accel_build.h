@@ -31,13 +31,13 @@ void accel_build(std::vector<AccelItem>& items, AccelTree& tree);
 
 // Appends the tree to `out`, 16 bytes per node: the box as six IEEE halves {min.x, min.y | min.z, max.x | max.y, max.z}
 // of the bounds multiplied by `scale` (a power of two chosen by the caller so that the scene fits the range of a half),
-// each rounded outward, and one word: RT_NODE_LEAF | leaf word for leaves, else the skip link (index into `out` of the
+// each rounded strictly outward, and one word: RT_NODE_LEAF | leaf word for leaves, else the skip link (index into `out` of the
 // next node in depth-first order that is not a descendant; one past the tree's last node for the links that leave it).
 // Nodes are in depth-first order; at every interior node the child on the near side for rays of `octant` (bit a set:
 // direction component a is negative) comes first.
 void accel_emit(const AccelTree& tree, int octant, float scale, std::vector<uint4>& out);
 
-// float -> IEEE half bits, rounded toward -infinity (up = false) or +infinity (up = true)
+// float -> IEEE half bits strictly below (up = false) or strictly above (up = true) x (infinities stay)
 uint16_t accel_half(float x, bool up);
 
 #endif

@@ -478,9 +478,10 @@ __device__ __forceinline__ float medium_t(const DevScene& S, uint32_t head, cons
 __device__ __forceinline__ void node_test(const DevScene& S, const BoxRay& R, float t_min, float t_max, uint32_t node,
                                           bool& hit, uint32_t& link) {
     const uint4 q = S.nodes[node];
-    // Box test (src/bounding_box.jl:70-84 form).  It only culls: the stored boxes are rounded outward, and the far
-    // distance is widened by 8 ulp so that rounding can never reject a box that the exact slab test of
-    // src/bounding_box.jl:20-67 accepts; NaNs (0 * Inf) drop out of fminf/fmaxf, which keeps the axis unconstrained.
+    // Box test (src/bounding_box.jl:70-84 form).  It only culls: the stored boxes are rounded strictly outward, and
+    // the far distance is widened by 8 ulp so that rounding can never reject a box that the exact slab test of
+    // src/bounding_box.jl:20-67 accepts.  A ray parallel to an axis gives +-Inf on that axis (inside the slab: -Inf and
+    // +Inf); 0 * Inf = NaN would need the origin exactly on a stored plane, outside every box of the reference.
     const v2f a = (__builtin_convertvector(__builtin_bit_cast(v2h, q.x), v2f) - R.o_xy) * R.i_xy; // x0, y0
     const v2f b = (__builtin_convertvector(__builtin_bit_cast(v2h, q.y), v2f) - R.o_zx) * R.i_zx; // z0, x1
     const v2f c = (__builtin_convertvector(__builtin_bit_cast(v2h, q.z), v2f) - R.o_yz) * R.i_yz; // y1, z1

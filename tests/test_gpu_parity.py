@@ -173,6 +173,26 @@ def test_sample_sharding_sums_to_the_full_frame(scenes):
         np.testing.assert_allclose(img, full, rtol=2e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("name", ["cornell_smoke_box", "cu_cover2", "teapot"])
+def test_degenerate_rays_terminate_and_match(name, scenes):
+    """zero, axis-parallel, huge, infinite and NaN ray components: the stackless walk must end (node indices only grow)
+    and the closest hit must still be the oracle's"""
+    world, kw, dev, ref = scenes(name)
+    cam = kw["camera"]
+    base = O.primary_rays(cam, 8, 8, 8, 8)
+    o = base[0, :3].copy()
+    rays = []
+    for d in ([0, 0, 0], [1, 0, 0], [0, -1, 0], [0, 0, 1], [1e30, 1e30, 1e30], [1e-30, -1e-30, 1e-30], [-0.0, 0.0, -1.0],
+              [np.inf, 0, 0], [np.nan, 1, 0], [np.nan, np.nan, np.nan], [1, np.inf, -np.inf]):
+        rays.append(np.concatenate([o, np.asarray(d, F), [0.5]]))
+    for oo in ([np.nan, 0, 0], [np.inf, 0, 0], [1e30, -1e30, 0], [0, 0, 0]):
+        rays.append(np.concatenate([np.asarray(oo, F), base[5, 3:6], [0.5]]))
+    rays = np.asarray(rays, F)
+    a, b = ref.trace_rays(rays), dev.trace_rays(rays)
+    np.testing.assert_array_equal(a["prim_id"], b["prim_id"])
+    np.testing.assert_array_equal(bits(a["t"]), bits(b["t"]))
+
+
 def test_device_output_stage_matches_host_quantisation(scenes):
     """rt_finalize_rgb8 (clamp01 + N0f8 on the device) == rt_finalize followed by the host quantisation"""
     import torch
