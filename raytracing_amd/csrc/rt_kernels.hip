@@ -506,7 +506,9 @@ __device__ __forceinline__ void node_step(const DevScene& S, const BoxRay& R, fl
 __device__ __forceinline__ void media_closest(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max,
                                               const RngKey& key, Closest& best) {
     if (S.medium_size == 0u) return;
-    uint32_t node = S.medium_root + layout_base(S, d);
+    // always the first layout: the lanes of a wave then meet the same medium in the same step of the loop (the medium
+    // test is long; with per-octant orders half the wave would sit out each of its executions)
+    uint32_t node = S.medium_root;
     const uint32_t end = node + S.medium_size;
     BoxRay R;
     box_frame(S, o, d, R);
