@@ -145,13 +145,14 @@ struct Builder {
     }
 
     // Object (possibly wrapped: ConstantMedium{Transform{shape}}) -> one device primitive.  Returns false on error.
-    bool make_prim(int oi, uint32_t rank, int top, int sub, bool nested, uint32_t& out) {
+    // outer_xf: transform index + 1 of the Transform around the nested tree the object is taken out of (0: none)
+    bool make_prim(int oi, uint32_t rank, int top, int sub, bool nested, uint32_t outer_xf, uint32_t& out) {
         if (!valid_obj(oi)) return fail(RT_EINVAL, "object index out of range");
         const rtObject* o = &D.objects[oi];
         bool medium = false;
         float neg_inv_density = 0.0f;
         int material = -1, medium_oi = -1;
-        uint32_t xf = 0;
+        uint32_t xf = outer_xf;
         if (o->kind == RT_CONSTANT_MEDIUM) {
             if (nested) return fail(RT_EUNSUPPORTED, "ConstantMedium inside a nested BVHTree is not supported");
             medium = true;
@@ -277,9 +278,22 @@ struct Builder {
         std::memcpy(out, box, sizeof(box));
     }
 
+    // A nested tree taken apart: its objects become primitives of the enclosing tree, each carrying the Transform of the
+    // nested tree.  hit(::Transform{BVHTree}) (src/transform.jl:104-116) takes the ray into the object frame once and
+    // keeps the closest object; testing every object with the same object-frame ray gives the same distances, the same
+    // winner (ranks = rank of the nested tree + position inside it) and the same hit record.
+    struct Inlined {
+        uint32_t xf;           // transform index + 1, 0 = none
+        const float* clip_box; // the box the reference walks for the whole nested tree (world frame)
+    };
+    bool inline_groups() const {
+        const char* e = std::getenv("RT_AMD_INLINE_GROUPS");
+        return !(e && e[0] == '0');
+    }
+
     // generic tree (src/BVH.jl)
     bool collect_generic(const rtBvh& T, int id, int depth, std::vector<AccelItem>& items, uint32_t rank_base,
-                         const std::vector<uint32_t>* rank_offset, bool nested, int nested_top) {
+                         const std::vector<uint32_t>* rank_offset, bool nested, int nested_top, const Inlined* inl = nullptr) {
         if (!check_node(T, id, depth)) return false;
         if (T.node_leaf[id - 1]) {
             int l = T.node_left[id - 1], r = T.node_right[id - 1];
@@ -288,17 +302,67 @@ struct Builder {
             uint32_t rank = rank_base + (rank_offset ? (*rank_offset)[(size_t)(l - 1)] : (uint32_t)(l - 1));
             int top = nested ? nested_top : (valid_obj(oi) ? top_pos[(size_t)oi] : -1);
             const float* leaf_box = T.node_bounds + 6 * (size_t)(id - 1);
+            if (!nested && valid_obj(oi) && inline_groups()) {
+                const rtObject* o = &D.objects[oi];
+                uint32_t xf = 0;
+                if (o->kind == RT_TRANSFORM && o->aux >= 0 && o->aux < D.n_transforms && valid_obj(o->child) &&
+                    D.objects[o->child].kind == RT_BVH) {
+                    xf = xform(o->aux) + 1u;
+                    o = &D.objects[o->child];
+                }
+                if (o->kind == RT_BVH && o->aux >= 0 && o->aux < D.n_groups) {
+                    const rtBvh& G = D.groups[o->aux];
+                    if (G.kind == 0 && G.n_objects > 0 && G.n_nodes > 0 && G.objects && G.node_bounds && G.node_left &&
+                        G.node_right && G.node_leaf) {
+                        std::vector<uint32_t> offsets;
+                        uint32_t acc = 0;
+                        for (int k = 0; k < G.n_objects; ++k) {
+                            offsets.push_back(acc);
+                            acc += flat_count(G.objects[k]);
+                        }
+                        Inlined ctx{xf, leaf_box};
+                        size_t saved = visited;
+                        visited = 0;
+                        bool ok = collect_generic(G, 1, 0, items, rank, &offsets, true, top, &ctx);
+                        visited = saved;
+                        return ok;
+                    }
+                }
+            }
             uint32_t prim;
-            if (!make_prim(oi, rank, top, nested ? oi : 0, nested, prim)) return false;
+            if (!make_prim(oi, rank, top, nested ? oi : 0, nested, inl ? inl->xf : 0u, prim)) return false;
             uint32_t head = H.prims[3 * (size_t)prim].x;
             bool instance = (head & 15u) == DP_INSTANCE;
+            float world_box[6];
+            if (inl) { // the object-frame box of the leaf, as a world-frame box inside the box of the whole nested tree
+                double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                double M[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+                if (inl->xf) for (int k = 0; k < 12; ++k) M[k] = (double)H.xforms[24 * (size_t)(inl->xf - 1) + k];
+                for (int corner = 0; corner < 8; ++corner) {
+                    double p[3];
+                    for (int a = 0; a < 3; ++a) p[a] = leaf_box[((corner >> a) & 1) ? 3 + a : a];
+                    for (int i = 0; i < 3; ++i) {
+                        double w = M[i] * p[0] + M[3 + i] * p[1] + M[6 + i] * p[2] + M[9 + i];
+                        lo[i] = std::min(lo[i], w); hi[i] = std::max(hi[i], w);
+                    }
+                }
+                bool ok = true;
+                for (int i = 0; i < 3; ++i) {
+                    double e = 1e-5 * (hi[i] - lo[i]) + 4e-6 * std::max(std::fabs(lo[i]), std::fabs(hi[i]));
+                    world_box[i] = std::max(std::nextafter((float)(lo[i] - e), -INFINITY), inl->clip_box[i]);
+                    world_box[3 + i] = std::min(std::nextafter((float)(hi[i] + e), INFINITY), inl->clip_box[3 + i]);
+                    if (!(world_box[i] <= world_box[3 + i])) ok = false;
+                }
+                if (!ok) std::memcpy(world_box, inl->clip_box, sizeof(world_box)); // NaN / infinite: the box of the whole tree
+                leaf_box = world_box;
+            }
             float box[6];
             tight_box(prim, leaf_box, box);
             add_item(items, box, prim, instance ? RT_LEAF_INSTANCE : ((head >> 8) ? RT_LEAF_XFORM : 0u));
             return true;
         }
-        return collect_generic(T, T.node_left[id - 1], depth + 1, items, rank_base, rank_offset, nested, nested_top) &&
-               collect_generic(T, T.node_right[id - 1], depth + 1, items, rank_base, rank_offset, nested, nested_top);
+        return collect_generic(T, T.node_left[id - 1], depth + 1, items, rank_base, rank_offset, nested, nested_top, inl) &&
+               collect_generic(T, T.node_right[id - 1], depth + 1, items, rank_base, rank_offset, nested, nested_top, inl);
     }
 
     // Builds the device tree over `items` and appends its eight layouts to dst[0..7]; every layout gets the same

@@ -219,3 +219,14 @@ def test_walk_never_culls_what_the_reference_visits(name, layouts):
                 n_must += 1
                 assert idx in visited, (name, k, idx, type(world[idx]).__name__)
     assert n_must > n_rays  # the rays do meet the scene
+
+
+def test_nested_tree_inlined_or_kept(monkeypatch):
+    world, kw = rt.get_scene("cover2", spp=1)
+    info, nodes, prim_top = scene_layout(world)
+    assert info.nested == 0                              # the 1000 spheres of the Transform{BVHTree} sit in the main tree
+    monkeypatch.setenv("RT_AMD_INLINE_GROUPS", "0")
+    info2, nodes2, prim_top2 = scene_layout(world)
+    assert info2.nested == 1 and info2.n_prims == info.n_prims + 1      # + the instance primitive
+    assert info2.surface_size < info.surface_size
+    assert sorted(set(prim_top)) == sorted(set(prim_top2))

@@ -193,6 +193,27 @@ def test_degenerate_rays_terminate_and_match(name, scenes):
     np.testing.assert_array_equal(bits(a["t"]), bits(b["t"]))
 
 
+def test_nested_tree_kept_as_instance(scenes, monkeypatch):
+    """By default the objects of a Transform{BVHTree} are taken into the enclosing device tree; with
+    RT_AMD_INLINE_GROUPS=0 the tree stays a nested instance (entered and left by the extend kernel).  Same image."""
+    world, kw, dev, ref = scenes("cover2")
+    cam, pat, bg = kw["camera"], kw["pattern"], kw["background"]
+    W, H = 64, 48
+    want = ref.render(cam, pat, bg, W, H)
+    monkeypatch.setenv("RT_AMD_INLINE_GROUPS", "0")
+    nested = rt.DeviceScene(world)
+    try:
+        img, _ = nested.render(cam, pat, bg, W, H)
+        rays = O.primary_rays(cam, W, H, 64, 64)
+        a, b = ref.trace_rays(rays), nested.trace_rays(rays)
+    finally:
+        nested.close()
+    np.testing.assert_array_equal(bits(img), bits(want))
+    np.testing.assert_array_equal(a["prim_id"], b["prim_id"])
+    np.testing.assert_array_equal(a["sub_id"], b["sub_id"])
+    np.testing.assert_array_equal(bits(a["t"]), bits(b["t"]))
+
+
 def test_device_output_stage_matches_host_quantisation(scenes):
     """rt_finalize_rgb8 (clamp01 + N0f8 on the device) == rt_finalize followed by the host quantisation"""
     import torch
