@@ -224,11 +224,14 @@ uint16_t accel_half(float x, bool up) {
 
 void accel_emit(const AccelTree& tree, int octant, float scale, std::vector<uint4>& out) {
     if (tree.nodes.empty()) return;
-    auto pack = [scale](const float* b, uint32_t word) {
-        uint16_t h[6];
-        for (int a = 0; a < 3; ++a) { h[a] = accel_half(b[a] * scale, false); h[3 + a] = accel_half(b[3 + a] * scale, true); }
-        return make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
-                          (uint32_t)h[4] | ((uint32_t)h[5] << 16), word);
+    // one word per axis: the plane a ray of this octant meets first in the low half, the other one in the high half
+    auto pack = [scale, octant](const float* b, uint32_t word) {
+        uint32_t w[3];
+        for (int a = 0; a < 3; ++a) {
+            uint32_t lo = accel_half(b[a] * scale, false), hi = accel_half(b[3 + a] * scale, true);
+            w[a] = ((octant >> a) & 1) ? (hi | (lo << 16)) : (lo | (hi << 16));
+        }
+        return make_uint4(w[0], w[1], w[2], word);
     };
     std::vector<int32_t> stack;
     stack.push_back(0);

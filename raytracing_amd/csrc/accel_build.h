@@ -29,8 +29,9 @@ struct AccelTree {
 
 void accel_build(std::vector<AccelItem>& items, AccelTree& tree);
 
-// Appends the tree to `out`, 16 bytes per node: the box as six IEEE halves {min.x, min.y | min.z, max.x | max.y, max.z}
-// of the bounds multiplied by `scale` (a power of two chosen by the caller so that the scene fits the range of a half),
+// Appends the tree to `out`, 16 bytes per node: the box as six IEEE halves, one word per axis {near | far << 16} where
+// near is the plane of that axis a ray of `octant` meets first (min for a positive direction component, max for a
+// negative one), of the bounds multiplied by `scale` (a power of two chosen by the caller so that the scene fits the range of a half),
 // each rounded strictly outward, and one word: RT_NODE_LEAF | leaf word for leaves, else the skip link (index into `out` of the
 // next node in depth-first order that is not a descendant; one past the tree's last node for the links that leave it).
 // Nodes are in depth-first order; at every interior node the child on the near side for rays of `octant` (bit a set:

@@ -2,8 +2,9 @@
 // and the gfx950 kernels (rt_kernels.hip).
 //
 // Layout in HBM (scenes of the size the reference ships stay L2-resident):
-//   nodes   : 16 B per node = one uint4: the box as six IEEE halves (x: min.x | min.y << 16, y: min.z | max.x << 16,
-//             z: max.y | max.z << 16) of the bounds times node_scale, rounded outward, and a link word w:
+//   nodes   : 16 B per node = one uint4: the box as six IEEE halves, one word per axis (near | far << 16: the plane a
+//             ray of the layout's octant meets first, then the other one; layout 0 = min | max << 16) of the bounds
+//             times node_scale, rounded strictly outward, and a link word w:
 //             leaves carry RT_NODE_LEAF | (primitive index + 1) | RT_LEAF_INSTANCE / RT_LEAF_XFORM flags, interior nodes
 //             the skip link.  Nodes are stored in depth-first pre-order.  Traversal is stackless: an interior node
 //             whose box is hit continues at node+1 (its first child), one that is missed at its skip link (the next

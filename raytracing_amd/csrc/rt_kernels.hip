@@ -325,19 +325,17 @@ __device__ __forceinline__ uint32_t first_active_lane() {
 }
 
 // The ray as the box test wants it: origin times the power of two the node boxes were scaled by, and 1/d divided by
-// it (scaling by a power of two is exact, so the distances come out as with unscaled boxes), paired up the way the six
-// half-precision bounds of a node are stored: (min.x, min.y) (min.z, max.x) (max.y, max.z).  The reciprocal is the
+// it (scaling by a power of two is exact, so the distances come out as with unscaled boxes), used for both planes of an axis at once
+// (a node stores the two planes of an axis in one word).  The reciprocal is the
 // hardware approximation (1 ulp): the box test only culls, and its far distance is widened by more than that.
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 struct BoxRay {
-    v2f o_xy, o_zx, o_yz, i_xy, i_zx, i_yz;
+    f3 o, i;
 };
 __device__ __forceinline__ void box_frame(const DevScene& S, f3 o, f3 d, BoxRay& R) {
-    f3 os = o * S.node_scale;
-    f3 is = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)) * S.inv_node_scale;
-    R.o_xy = (v2f){os.x, os.y}; R.o_zx = (v2f){os.z, os.x}; R.o_yz = (v2f){os.y, os.z};
-    R.i_xy = (v2f){is.x, is.y}; R.i_zx = (v2f){is.z, is.x}; R.i_yz = (v2f){is.y, is.z};
+    R.o = o * S.node_scale;
+    R.i = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)) * S.inv_node_scale;
 }
 
 // Traversal of the flattened SceneManager.  Equivalent to hit(::SceneManager, ray, t_min, t_max)
@@ -366,7 +364,8 @@ struct Walker {
 
 // first node of the layout that orders children near side first for direction d (one layout per octant)
 __device__ __forceinline__ uint32_t layout_base(const DevScene& S, f3 d) {
-    uint32_t octant = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    // by sign bit, so that -0.0 (reciprocal -Inf) takes the layout whose planes are ordered for a negative component
+    uint32_t octant = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
     return octant * S.n_nodes;
 }
 __device__ __forceinline__ void walker_start(Walker& W, const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max) {
@@ -475,6 +474,10 @@ __device__ __forceinline__ float medium_t(const DevScene& S, uint32_t head, cons
 // One node: fetch + box test.  `hit`: the ray passes the node's box inside (t_min, t_max); `link`: the node's link word
 // (leaf word with RT_NODE_LEAF set, or the skip link).  The walk continues at node + 1 after a leaf or a hit interior
 // node and at `link` after a missed interior node; it is over when it reaches the end index of its tree.
+// SORTED: the node belongs to the layout of the ray's own octant, whose words hold {near plane, far plane} per axis in
+// the order the ray meets them -- no min/max per axis.  Otherwise (layout 0 walked by any ray) the planes are ordered
+// per ray.
+template <bool SORTED>
 __device__ __forceinline__ void node_test(const DevScene& S, const BoxRay& R, float t_min, float t_max, uint32_t node,
                                           bool& hit, uint32_t& link) {
     const uint4 q = S.nodes[node];
@@ -482,20 +485,27 @@ __device__ __forceinline__ void node_test(const DevScene& S, const BoxRay& R, fl
     // the far distance is widened by 8 ulp so that rounding can never reject a box that the exact slab test of
     // src/bounding_box.jl:20-67 accepts.  A ray parallel to an axis gives +-Inf on that axis (inside the slab: -Inf and
     // +Inf); 0 * Inf = NaN would need the origin exactly on a stored plane, outside every box of the reference.
-    const v2f a = (__builtin_convertvector(__builtin_bit_cast(v2h, q.x), v2f) - R.o_xy) * R.i_xy; // x0, y0
-    const v2f b = (__builtin_convertvector(__builtin_bit_cast(v2h, q.y), v2f) - R.o_zx) * R.i_zx; // z0, x1
-    const v2f c = (__builtin_convertvector(__builtin_bit_cast(v2h, q.z), v2f) - R.o_yz) * R.i_yz; // y1, z1
-    float tnear = fmaxf(fmaxf(fminf(a.x, b.y), fminf(a.y, c.x)), fmaxf(fminf(b.x, c.y), t_min));
-    float tfar = fminf(fminf(fmaxf(a.x, b.y), fmaxf(a.y, c.x)), fminf(fmaxf(b.x, c.y), t_max));
+    const v2f a = (__builtin_convertvector(__builtin_bit_cast(v2h, q.x), v2f) - (v2f){R.o.x, R.o.x}) * (v2f){R.i.x, R.i.x};
+    const v2f b = (__builtin_convertvector(__builtin_bit_cast(v2h, q.y), v2f) - (v2f){R.o.y, R.o.y}) * (v2f){R.i.y, R.i.y};
+    const v2f c = (__builtin_convertvector(__builtin_bit_cast(v2h, q.z), v2f) - (v2f){R.o.z, R.o.z}) * (v2f){R.i.z, R.i.z};
+    float tnear, tfar;
+    if (SORTED) {
+        tnear = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, t_min));
+        tfar = fminf(fminf(a.y, b.y), fminf(c.y, t_max));
+    } else {
+        tnear = fmaxf(fmaxf(fminf(a.x, a.y), fminf(b.x, b.y)), fmaxf(fminf(c.x, c.y), t_min));
+        tfar = fminf(fminf(fmaxf(a.x, a.y), fmaxf(b.x, b.y)), fminf(fmaxf(c.x, c.y), t_max));
+    }
     tfar = __builtin_fmaf(fabsf(tfar), 4.8e-7f, tfar);
     hit = tnear <= tfar;
     link = q.w;
 }
+template <bool SORTED>
 __device__ __forceinline__ void node_step(const DevScene& S, const BoxRay& R, float t_min, float t_max, uint32_t& node,
                                           uint32_t& leaf) {
     bool hit;
     uint32_t link;
-    node_test(S, R, t_min, t_max, node, hit, link);
+    node_test<SORTED>(S, R, t_min, t_max, node, hit, link);
     const bool is_leaf = (int32_t)link < 0;
     node = (hit || is_leaf) ? node + 1u : link;
     leaf = (hit && is_leaf) ? (link & ~RT_NODE_LEAF) : 0u;
@@ -515,7 +525,7 @@ __device__ __forceinline__ void media_closest(const DevScene& S, f3 o, f3 d, flo
     if (best.t != INF) t_max = best.t;
     while (node != end) {
         uint32_t leaf;
-        node_step(S, R, t_min, t_max, node, leaf);
+        node_step<false>(S, R, t_min, t_max, node, leaf);
         if (leaf) {
             uint32_t prim = (leaf & RT_LEAF_PRIM_MASK) - 1u;
             uint4 head;
@@ -541,7 +551,7 @@ __device__ __forceinline__ void walker_step(Walker& W, const DevScene& S, Counte
     if (W.node == W.end && W.ret != RT_NODE_NONE) walker_return(W, S);
     if (W.node != W.end) {
         if (COUNT) cnt.nodes++;
-        node_step(S, W.R, W.t_min, W.t_max, W.node, W.leaf);
+        node_step<true>(S, W.R, W.t_min, W.t_max, W.node, W.leaf);
     }
 }
 
@@ -1152,7 +1162,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                     if (COUNT) { cnt.nodes++; cnt.node_waves += first_active_lane(); }
                     bool hit;
                     uint32_t link;
-                    node_test(S, R, t_min, t_max, node, hit, link);
+                    node_test<true>(S, R, t_min, t_max, node, hit, link);
                     // branch-free bookkeeping: where the walk goes on, and the leaf queue (a shift register)
                     const bool is_leaf = (int32_t)link < 0;
                     const bool push = hit && is_leaf;

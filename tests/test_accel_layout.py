@@ -14,10 +14,15 @@ PRIM_MASK = 0x1FFFFFFF
 SCENES = ["cornell_box", "cornell_smoke_box", "cover1", "cu_cover2", "cover2", "teapot"]
 
 
-def boxes_of(nodes):
-    """(..., 6) float32 {min.xyz, max.xyz} of the stored half-precision boxes"""
-    h = nodes[..., :3].copy().view(np.float16).astype(np.float32)  # (.., 6): lo.x lo.y lo.z hi.x hi.y hi.z
-    return h
+def boxes_of(nodes, octant=0):
+    """(..., 6) float32 {min.xyz, max.xyz} of the stored half-precision boxes of the layout of `octant`: word a holds
+    the two planes of axis a, the one a ray of that octant meets first in the low half"""
+    h = nodes[..., :3].copy().view(np.float16).astype(np.float32)      # (.., 6): x0 x1 y0 y1 z0 z1 in stored order
+    first, second = h[..., 0::2], h[..., 1::2]
+    neg = np.array([(octant >> a) & 1 for a in range(3)], bool)
+    lo = np.where(neg, second, first)
+    hi = np.where(neg, first, second)
+    return np.concatenate([lo, hi], axis=-1)
 
 
 def subtree_end(link, i):
@@ -46,7 +51,7 @@ def test_structure_and_coverage(name, layouts):
     ref = None
     for o in range(8):
         link = nodes[o, :, 3].astype(np.int64)
-        box = boxes_of(nodes[o])
+        box = boxes_of(nodes[o], o)
         base = o * N
         # every primitive is the leaf of exactly one node of the layout
         leaves = link[(link & LEAF) != 0]
@@ -76,7 +81,7 @@ def test_structure_and_coverage(name, layouts):
                 stack += [c1, c2]
             assert seen == size and subtree_end(rel, root) == root + size
         # the eight layouts hold the same nodes (boxes, leaf words), only in different orders
-        key = np.concatenate([nodes[o, :, :3], np.where((link & LEAF) != 0, link, 0).astype(np.uint32)[:, None]], axis=1)
+        key = np.concatenate([box.view(np.uint32), np.where((link & LEAF) != 0, link, 0).astype(np.uint32)[:, None]], axis=1)
         key = key[np.lexsort(key.T[::-1])]
         if ref is None:
             ref = key
@@ -87,14 +92,16 @@ def test_structure_and_coverage(name, layouts):
         r = info.surface_root
         rel0 = nodes[0, :, 3].astype(np.int64)
         rel7 = np.where((nodes[7, :, 3] & LEAF) != 0, nodes[7, :, 3].astype(np.int64), nodes[7, :, 3].astype(np.int64) - 7 * N)
-        a, b = boxes_of(nodes[0]), boxes_of(nodes[7])
+        a, b = boxes_of(nodes[0], 0), boxes_of(nodes[7], 7)
         assert np.array_equal(a[r + 1], b[subtree_end(rel7, r + 1)])
         assert np.array_equal(a[subtree_end(rel0, r + 1)], b[r + 1])
 
 
 def walk(nodes, info, octant, root, size, o, d, t_min=0.001):
     """the stackless walk of rt_kernels.hip for one ray, in float32 like the kernel (exact division instead of the
-    hardware reciprocal); returns the list of leaf words visited with the box passed"""
+    hardware reciprocal): the layout of the ray's octant stores every axis as (near plane, far plane), so the entry
+    distance is the largest of the first halves and the exit distance the smallest of the second halves.  Returns the
+    list of leaf words visited with the box passed."""
     N = info.nodes_per_layout
     F = np.float32
     scale = F(info.node_scale)
@@ -102,17 +109,17 @@ def walk(nodes, info, octant, root, size, o, d, t_min=0.001):
     with np.errstate(divide="ignore"):
         inv = (F(1) / d).astype(F) * (F(1) / scale)
     link = nodes[octant, :, 3]
-    box = boxes_of(nodes[octant])
+    planes = nodes[octant, :, :3].copy().view(np.float16).astype(np.float32)     # x near, x far, y near, y far, z near, z far
     node = octant * N + root
     end = node + size
     out = []
     while node != end:
         i = node - octant * N
         with np.errstate(invalid="ignore"):
-            t0 = (box[i, :3] - os_) * inv
-            t1 = (box[i, 3:] - os_) * inv
-        tnear = max(np.fmax.reduce(np.fmin(t0, t1)), F(t_min))
-        tfar = np.fmin.reduce(np.fmax(t0, t1))
+            t0 = (planes[i, 0::2] - os_) * inv
+            t1 = (planes[i, 1::2] - os_) * inv
+        tnear = max(np.fmax.reduce(t0), F(t_min))
+        tfar = np.fmin.reduce(t1)
         with np.errstate(invalid="ignore"):
             tfar = tfar + abs(tfar) * F(4.8e-7)
         hit = tnear <= tfar
@@ -209,7 +216,7 @@ def test_walk_never_culls_what_the_reference_visits(name, layouts):
             d = (target - o).astype(np.float32)
             if k % 16 == 3:
                 d[rng.integers(3)] = 0.0
-        octant = int(d[0] < 0) | (int(d[1] < 0) << 1) | (int(d[2] < 0) << 2)
+        octant = int(np.signbit(d[0])) | (int(np.signbit(d[1])) << 1) | (int(np.signbit(d[2])) << 2)
         visited = set()
         for root, size in ((info.surface_root, info.surface_size), (info.medium_root, info.medium_size)):
             if size:
