@@ -178,6 +178,7 @@ struct Stats {
 struct Ctx { /* identifies the random stream of the path being traced */
     uint32_t pixel = 0, sample = 0, seed32 = 0, bounce = 0;
     Stats* st = nullptr;
+    std::vector<Ray>* ray_log = nullptr; /* when set, trace() records every ray it casts */
     void draw(uint32_t purpose, uint32_t k, float out[4]) const {
         uint32_t v[4] = {pixel, sample, rng_counter(bounce, purpose, k), seed32};
         pcg4d(v);
@@ -947,6 +948,7 @@ V3 trace(const ref_scene& S, Ray ray, V3 background, int depth, Ctx& c) {
     V3 color = v3(0.0f);
     c.bounce = 0;
     while (depth > 0) {
+        if (c.ray_log) c.ray_log->push_back(ray);
         Hit h = hit_scene(S, ray, 0.001f, INF, c);
         if (h.t == INF) return color + acc * background;
         Ray scattered;
@@ -977,7 +979,8 @@ Ray get_ray(const refCamera& cam, float s, float t, Ctx& c) {
 }
 
 V3 path_radiance(const ref_scene& S, const refCamera& cam, const float* pattern, int i, int j, int n, int width,
-                 int height, V3 background, int max_depth, uint32_t seed32, Stats* st) {
+                 int height, V3 background, int max_depth, uint32_t seed32, Stats* st,
+                 std::vector<Ray>* ray_log = nullptr) {
     /* Ray_Tracing.jl:83-88 */
     float dx = pattern[2 * n], dy = pattern[2 * n + 1];
     float s = ((float)i + dx) / (float)(width - 1);
@@ -987,6 +990,7 @@ V3 path_radiance(const ref_scene& S, const refCamera& cam, const float* pattern,
     c.sample = (uint32_t)n;
     c.seed32 = seed32;
     c.st = st;
+    c.ray_log = ray_log;
     Ray r = get_ray(cam, s, t, c);
     return trace(S, r, background, max_depth, c);
 }
@@ -1148,6 +1152,24 @@ int ref_trace_paths(ref_scene* S, const refCamera* cam, const float* pattern, in
         radiance[3 * k] = c.x; radiance[3 * k + 1] = c.y; radiance[3 * k + 2] = c.z;
     }
     return 0;
+}
+
+/* The rays (origin, direction, time) that one path casts, bounce by bounce: for finding the bounce at which
+ * another implementation of the same path parts from this one. */
+int ref_path_rays(ref_scene* S, const refCamera* cam, const float* pattern, int n, const float background[3], int width,
+                  int height, int max_depth, uint64_t seed, int i, int j, int s, float* rays, int max_rays) {
+    if (!S || !cam || !pattern || !rays) { g_err = "bad argument"; return -1; }
+    if (i < 0 || i >= width || j < 0 || j >= height || s < 0 || s >= n) { g_err = "path id out of range"; return -1; }
+    std::vector<Ray> log;
+    path_radiance(*S, *cam, pattern, i, j, s, width, height, v3(background[0], background[1], background[2]),
+                  max_depth, fold_seed(seed), nullptr, &log);
+    int m = (int)log.size() < max_rays ? (int)log.size() : max_rays;
+    for (int k = 0; k < m; ++k) {
+        const Ray& r = log[k];
+        float* q = &rays[7 * k];
+        q[0] = r.o.x; q[1] = r.o.y; q[2] = r.o.z; q[3] = r.d.x; q[4] = r.d.y; q[5] = r.d.z; q[6] = r.time;
+    }
+    return m;
 }
 
 int ref_trace_rays(ref_scene* S, const float* rays, int n, float tmin, float tmax, uint64_t seed, int32_t* prim_id,

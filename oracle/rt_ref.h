@@ -147,6 +147,12 @@ int ref_trace_paths(ref_scene*, const refCamera*, const float* pattern, int n,
                     const float background[3], int width, int height, int max_depth, uint64_t seed,
                     const int32_t* ids, int n_paths, float* radiance /*3 x n_paths*/);
 
+/* the rays one path casts, bounce by bounce (7 floats each: origin, direction, time); returns how many were
+ * written (at most max_rays) or -1.  For finding the bounce at which another implementation parts from this one. */
+int ref_path_rays(ref_scene*, const refCamera*, const float* pattern, int n, const float background[3],
+                  int width, int height, int max_depth, uint64_t seed, int i, int j, int s, float* rays,
+                  int max_rays);
+
 /* closest hit of fixed rays against the whole SceneManager (src/scene_manager.jl:40-53).
  * rays: 7 floats each (origin, direction, time).  prim_id = position in `top`, -1 on miss. */
 int ref_trace_rays(ref_scene*, const float* rays, int n, float tmin, float tmax, uint64_t seed,

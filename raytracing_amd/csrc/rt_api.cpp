@@ -42,6 +42,7 @@ struct rtScene {
     float* d_pattern = nullptr; size_t pattern_cap = 0;
     float4* d_radiance = nullptr; size_t radiance_cap = 0; // one entry per path of the batch in flight
     float4* d_pool = nullptr;   size_t pool_cap = 0;   // path state planes of the wavefront renderer
+    uint32_t* d_redo = nullptr; size_t redo_cap = 0;   // slots on hold (PathPool::redo)
     uint32_t* d_sync = nullptr;                        // [0] slot dispenser head, [1..] active-slot counts per bounce
     uint32_t* h_sync = nullptr;                        // pinned mirror of the activity flag
     uint32_t h_init[RT_SYNC_WORDS];                    // staging of the initial sync array
@@ -149,6 +150,7 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     if (st == RT_OK) st = upload(s, H.nodes, &s->dev.nodes);
     if (st == RT_OK) st = upload(s, H.prims, &s->dev.prims);
     if (st == RT_OK) st = upload(s, H.prim_inv, &s->dev.prim_inv);
+    if (st == RT_OK) st = upload(s, H.prim_box, &s->dev.prim_box);
     if (st == RT_OK) st = upload(s, H.xforms, &s->dev.xforms);
     if (st == RT_OK) st = upload(s, H.materials, &s->dev.materials);
     if (st == RT_OK) st = upload(s, H.textures, &s->dev.textures);
@@ -210,6 +212,7 @@ int rt_scene_destroy(rtScene* s) {
     if (s->d_pattern) (void)hipFree(s->d_pattern);
     if (s->d_radiance) (void)hipFree(s->d_radiance);
     if (s->d_pool) (void)hipFree(s->d_pool);
+    if (s->d_redo) (void)hipFree(s->d_redo);
     if (s->d_sync) (void)hipFree(s->d_sync);
     if (s->h_sync) (void)hipHostFree(s->h_sync);
     if (s->events) {
@@ -259,7 +262,10 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
     if (st != RT_OK) return st;
     st = ensure(&s->d_radiance, &s->radiance_cap, (size_t)cols * P.n_pixels);
     if (st != RT_OK) return st;
+    st = ensure(&s->d_redo, &s->redo_cap, (size_t)pool.n_slots);
+    if (st != RT_OK) return st;
     pool.q = s->d_pool;
+    pool.redo = s->d_redo;
     HIP_TRY(hipMemcpyAsync(s->d_pattern, pattern, (size_t)2 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, stream));
     bool count = (flags & RT_FLAG_COUNTERS) != 0;
     if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), stream));
@@ -297,6 +303,7 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
         // bounces in batches and stops after the first batch that ends with none.
         for (uint64_t bounce = 0;; bounce += BOUNCE_BATCH) {
             HIP_TRY(hipMemsetAsync(s->d_sync + 2, 0, BOUNCE_BATCH * sizeof(uint32_t), stream));
+            if (bounce != 0) rt_launch_redo(&s->dev, &pool, s->d_sync, stream);
             for (uint32_t b = 0; b < BOUNCE_BATCH; ++b)
                 rt_launch_bounce(&s->dev, &cam, s->d_pattern, &P, &pool, extend_blocks, s->d_radiance, s->d_sync,
                                  s->d_sync + 2u + b, s->d_counters, count, timing ? s->events + 3u * b : nullptr, stream);

@@ -26,6 +26,12 @@
 #define RT_NODE_LEAF 0x80000000u    // node link word: the node is a leaf
 #define RT_LEAF_INSTANCE 0x40000000u // leaf word flag: the primitive is a nested tree (Transform{BVHTree})
 #define RT_LEAF_XFORM 0x20000000u    // leaf word flag: the primitive sits in a Transform (prim_inv holds its inverse matrix)
+// prim_box[4 * prim + 0..1] = {min.xyz, max.x}, {max.yz, flags, 0}: the leaf box of the primitive in its top-level
+// tree (for an object of a nested tree: the box of that tree's leaf), tested with the ray as cast;
+// prim_box[4 * prim + 2..3] = {min.xyz, max.x}, {max.yz, 0, 0}: the leaf box inside a nested tree, tested with the
+// ray taken into the frame of the Transform around that tree
+#define RT_BOX_OUTER 1u // flags: the first box is present
+#define RT_BOX_INNER 2u // flags: the second box is present
 #define RT_LEAF_PRIM_MASK 0x1FFFFFFFu // leaf word: primitive index + 1
 
 enum DevPrimKind {
@@ -50,6 +56,7 @@ struct DevImage {
 struct DevScene {
     const uint4* nodes;
     const uint4* prims;
+    const float4* prim_box;      // 4 per primitive: the boxes the reference walks for it (RT_BOX_* below)
     const float4* prim_inv;      // 3 per primitive: inverse 3x4 matrix (column-major) of its Transform, zeros without one
     const float* xforms;
     const uint4* materials;      // {type | flags, texture, bits(fuzz), bits(eta)}

@@ -18,10 +18,12 @@ struct RtCameraDev { // same field order as rtCamera (src/camera.jl:3-14)
 #define RT_DISP_STRIDE 32u // words between dispensers (128 bytes)
 #define RT_SLOT_DISP 64u   // slot dispensers of the extend kernel (each hands out one contiguous share of the slots)
 #define RT_SLOT_DISP_BASE (RT_DISP_BASE + RT_DISP_MAX * RT_DISP_STRIDE)
-#define RT_SYNC_WORDS (RT_SLOT_DISP_BASE + RT_SLOT_DISP * RT_DISP_STRIDE)
+#define RT_REDO_COUNT (RT_SLOT_DISP_BASE + RT_SLOT_DISP * RT_DISP_STRIDE) // entries in PathPool::redo; + 1: finished workgroups of rt_redo_kernel
+#define RT_SYNC_WORDS (RT_REDO_COUNT + RT_DISP_STRIDE)
 
 struct PathPool { // per-slot path state, five float4 planes of n_slots entries each (see rt_kernels.hip)
     float4* q;
+    uint32_t* redo; // n_slots entries: slots on hold, whose ray rt_redo_kernel walks again
     uint32_t n_slots;
 };
 
@@ -51,6 +53,8 @@ void rt_launch_init(const RtCameraDev* cam, const float* d_pattern, const RtRend
 void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, const float* d_pattern, const RtRenderParams* P,
                       const PathPool* pool, uint32_t extend_blocks, float4* d_radiance, uint32_t* d_sync, uint32_t* d_active,
                       unsigned long long* d_counters, bool count, hipEvent_t* timing, hipStream_t stream);
+// settles the slots that the shade kernel put on hold since the last call; to be enqueued between batches of bounces
+void rt_launch_redo(const DevScene* S, const PathPool* pool, uint32_t* d_sync, hipStream_t stream);
 void rt_launch_sum(const RtRenderParams* P, const float4* d_radiance, float* d_accum, int first_batch, hipStream_t stream);
 void rt_launch_finalize(const float* d_accum, float inv_n, size_t image_floats, float* d_out, hipStream_t stream);
 void rt_launch_finalize_rgb8(const float* d_accum, float inv_n, int width, int height, uint8_t* d_out, hipStream_t stream);

@@ -331,11 +331,107 @@ __device__ __forceinline__ uint32_t first_active_lane() {
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 struct BoxRay {
-    f3 o, i;
+    f3 i;      // 1/d divided by the node scale
+    f3 cn, cf; // -(origin * node scale) * i, lowered / raised by the rounding slack of that product (near / far planes)
 };
 __device__ __forceinline__ void box_frame(const DevScene& S, f3 o, f3 d, BoxRay& R) {
-    R.o = o * S.node_scale;
     R.i = mk3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)) * S.inv_node_scale;
+    f3 oi = (o * S.node_scale) * R.i;
+    // plane distance = plane * i - oi in one fused operation; the rounding of oi (half an ulp of it, however small the
+    // distance) is taken out of the near distances and added to the far ones: 2^-22 |oi| each
+    f3 slack = mk3(fabsf(oi.x), fabsf(oi.y), fabsf(oi.z)) * 2.384185791015625e-07f;
+    R.cn = mk3(-oi.x - slack.x, -oi.y - slack.y, -oi.z - slack.z);
+    R.cf = mk3(-oi.x + slack.x, -oi.y + slack.y, -oi.z + slack.z);
+}
+
+// The reference's own box test (src/bounding_box.jl:20-67) for the one box per primitive whose outcome is not implied
+// by the device tree: the box of the leaf that holds the primitive.  The device tree only ever culls less than the
+// reference's trees; this test takes away what the reference culls on top of that -- a thin box (a rectangle's box is
+// 0.0002 thick) seen from far away, whose two plane distances round to the same float, fails `t_max <= t_min`, and so
+// does a ray that grazes a box within rounding of an edge.  The test passes iff min(t_max, far distances) >
+// max(t_min, near distances), NaN distances ignored, every distance computed as (plane - origin) / direction.
+//
+// Fast path, decisive for all but knife-edge rays: the distances from reciprocals (each within 2^-22 of the
+// reference's, relative), moved inward by more than that, must leave every far distance above every near distance of
+// the OTHER axes (and above t_min); the two distances of one axis -- a few ulp apart when the box is thin -- are told
+// apart exactly instead: their numerators (plane - origin), which are the reference's own, differ by three ulp or more,
+// and then the quotients by the same direction component cannot round to one float.  Anything else (including every
+// non-finite or denormal distance, which fails these comparisons) goes through the reference's sequence itself.
+// MISSES: the caller's boxes are often missed outright (the candidates of a walk, as opposed to the box of a hit that
+// was found): an interval that is empty by more than the error of the fast distances is turned down on the fast path too.
+template <bool MISSES>
+__device__ __forceinline__ bool ref_box_pass(float4 b0, float4 b1, f3 o, f3 d, float t_min, float t_max) {
+    const f3 mn = mk3(b0.x, b0.y, b0.z), mx = mk3(b0.w, b1.x, b1.y);
+    if (MISSES && t_min == 0.001f) {
+        // A ray that starts inside the box, further than g from every plane (the ray of nearly every path inside the
+        // box of a scene-wide medium): per axis one plane lies behind the origin and one ahead, |plane - origin| > g as
+        // the reference computes it, so every near distance is negative and every far distance is above
+        // g / |direction component| >= 0.0011: the test comes down to t_max > t_min.
+        const float g = 0.0011f * fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+        if (o.x - mn.x > g && mx.x - o.x > g && o.y - mn.y > g && mx.y - o.y > g && o.z - mn.z > g && mx.z - o.z > g && g < INF)
+            return t_max > t_min;
+    }
+    {
+        const float C = 4e-7f, SEP = 3.6e-7f;
+        const v2f nx = (v2f){mn.x, mx.x} - (v2f){o.x, o.x}, ny = (v2f){mn.y, mx.y} - (v2f){o.y, o.y}, nz = (v2f){mn.z, mx.z} - (v2f){o.z, o.z};
+        const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
+        const v2f qx = nx * (v2f){ix, ix}, qy = ny * (v2f){iy, iy}, qz = nz * (v2f){iz, iz};
+        float lx = fminf(qx.x, qx.y), hx = fmaxf(qx.x, qx.y), ly = fminf(qy.x, qy.y), hy = fmaxf(qy.x, qy.y);
+        float lz = fminf(qz.x, qz.y), hz = fmaxf(qz.x, qz.y);
+        if (MISSES) {
+            const float T0 = fmaxf(fmaxf(lx, ly), fmaxf(lz, t_min)), T1 = fminf(fminf(hx, hy), fminf(hz, t_max));
+            if (T1 - T0 < -C * (fabsf(T1) + fabsf(T0)) && t_min > 1e-30f) return false;
+        }
+        lx = __builtin_fmaf(C, fabsf(lx), lx); ly = __builtin_fmaf(C, fabsf(ly), ly); lz = __builtin_fmaf(C, fabsf(lz), lz);
+        hx = __builtin_fmaf(-C, fabsf(hx), hx); hy = __builtin_fmaf(-C, fabsf(hy), hy); hz = __builtin_fmaf(-C, fabsf(hz), hz);
+        const bool cross = (hx > fmaxf(fmaxf(ly, lz), t_min)) && (hy > fmaxf(fmaxf(lx, lz), t_min)) && (hz > fmaxf(fmaxf(lx, ly), t_min)) &&
+                           (t_max > fmaxf(fmaxf(lx, ly), fmaxf(lz, t_min)));
+        const bool apart = (__builtin_fmaf(-SEP, fmaxf(fabsf(nx.x), fabsf(nx.y)), nx.y - nx.x) > 0.0f) &&
+                           (__builtin_fmaf(-SEP, fmaxf(fabsf(ny.x), fabsf(ny.y)), ny.y - ny.x) > 0.0f) &&
+                           (__builtin_fmaf(-SEP, fmaxf(fabsf(nz.x), fabsf(nz.y)), nz.y - nz.x) > 0.0f);
+        if (cross && apart && t_min > 1e-30f) return true;
+    }
+    float lo, hi;
+    lo = (mn.x - o.x) / d.x; hi = (mx.x - o.x) / d.x;
+    if (lo > hi) { float w = lo; lo = hi; hi = w; }
+    if (hi < t_max) t_max = hi;
+    if (lo > t_min) t_min = lo;
+    if (t_max <= t_min) return false;
+    lo = (mn.y - o.y) / d.y; hi = (mx.y - o.y) / d.y;
+    if (lo > hi) { float w = lo; lo = hi; hi = w; }
+    if (hi < t_max) t_max = hi;
+    if (lo > t_min) t_min = lo;
+    if (t_max <= t_min) return false;
+    lo = (mn.z - o.z) / d.z; hi = (mx.z - o.z) / d.z;
+    if (lo > hi) { float w = lo; lo = hi; hi = w; }
+    if (hi < t_max) t_max = hi;
+    if (lo > t_min) t_min = lo;
+    return !(t_max <= t_min);
+}
+// Does the reference reach primitive `prim` with the ray (o, d) as cast?  xf: index + 1 of the Transform around the
+// nested tree the primitive belongs to, if any.  t_max is the bound the ray was cast with: the reference tests with the
+// closest distance found so far, which differs from it only for boxes that lie behind that distance anyway.
+// b0, b1: the first two words of the primitive's record in prim_box (loaded by the caller, as early as it can)
+template <bool MISSES>
+__device__ __forceinline__ bool ref_reaches(const DevScene& S, uint32_t prim, float4 b0, float4 b1, uint32_t xf, f3 o, f3 d,
+                                            float t_min, float t_max) {
+    const float4* b = S.prim_box + 4u * prim;
+    const uint32_t flags = __float_as_uint(b1.z);
+    if ((flags & RT_BOX_OUTER) && !ref_box_pass<MISSES>(b0, b1, o, d, t_min, t_max)) return false;
+    if (flags & RT_BOX_INNER) {
+        if (xf) { // src/transform.jl:104-105
+            const float* T = S.xforms + 24u * (xf - 1u) + 12;
+            f3 no = apply_point(T, o), nd = apply_vec(T, d);
+            o = no; d = nd;
+        }
+        if (!ref_box_pass<MISSES>(b[2], b[3], o, d, t_min, t_max)) return false;
+    }
+    return true;
+}
+template <bool MISSES>
+__device__ __forceinline__ bool ref_reaches(const DevScene& S, uint32_t prim, uint32_t xf, f3 o, f3 d, float t_min, float t_max) {
+    const float4* b = S.prim_box + 4u * prim;
+    return ref_reaches<MISSES>(S, prim, b[0], b[1], xf, o, d, t_min, t_max);
 }
 
 // Traversal of the flattened SceneManager.  Equivalent to hit(::SceneManager, ray, t_min, t_max)
@@ -360,6 +456,7 @@ struct Walker {
     uint32_t node, end;        // next node to visit; the walk of the current tree is over at node == end
     uint32_t leaf;             // pending leaf word: (primitive index + 1) | flags, 0 = none
     Closest best;
+    float t_hi;                // t_max the ray was cast with
 };
 
 // first node of the layout that orders children near side first for direction d (one layout per octant)
@@ -378,11 +475,14 @@ __device__ __forceinline__ void walker_start(Walker& W, const DevScene& S, f3 o,
     W.end = W.node + S.surface_size;
     W.leaf = 0;
     W.best.t = INF; W.best.prim = 0xFFFFFFFFu; W.best.sx = 0; W.best.rank = 0;
+    W.t_hi = t_max;
 }
 __device__ __forceinline__ bool walker_finished(const Walker& W) { return W.leaf == 0u && W.node == W.end && W.ret == RT_NODE_NONE; }
 __device__ __forceinline__ bool walker_wants_leaf(const Walker& W) { return W.leaf != 0u; }
 __device__ __forceinline__ bool walker_wants_step(const Walker& W) { return W.leaf == 0u && !walker_finished(W); }
 
+// (floor_t, floor_rank): a hit the reference does not reach (ref_reaches) and everything that ranks before it are
+// left out when the walk is done again for the next closest hit; (-INF, 0) leaves out nothing.
 __device__ __forceinline__ void consider(Closest& best, float& t_max, float t, uint32_t prim, uint32_t sx, uint32_t rank) {
     if (t < best.t || (t == best.t && t != INF && rank > best.rank)) {
         best.t = t;
@@ -391,6 +491,10 @@ __device__ __forceinline__ void consider(Closest& best, float& t_max, float t, u
         best.rank = rank;
         t_max = t;
     }
+}
+__device__ __forceinline__ void consider(Closest& best, float& t_max, float t, uint32_t prim, uint32_t sx, uint32_t rank,
+                                         float floor_t, uint32_t floor_rank) {
+    if (t > floor_t || (t == floor_t && rank < floor_rank)) consider(best, t_max, t, prim, sx, rank);
 }
 
 // The two boundary probes of src/constant_medium.jl:30-35, hit(boundary, r, -Inf, Inf).t and
@@ -474,38 +578,32 @@ __device__ __forceinline__ float medium_t(const DevScene& S, uint32_t head, cons
 // One node: fetch + box test.  `hit`: the ray passes the node's box inside (t_min, t_max); `link`: the node's link word
 // (leaf word with RT_NODE_LEAF set, or the skip link).  The walk continues at node + 1 after a leaf or a hit interior
 // node and at `link` after a missed interior node; it is over when it reaches the end index of its tree.
-// SORTED: the node belongs to the layout of the ray's own octant, whose words hold {near plane, far plane} per axis in
-// the order the ray meets them -- no min/max per axis.  Otherwise (layout 0 walked by any ray) the planes are ordered
-// per ray.
-template <bool SORTED>
+// The node must belong to the layout of the ray's own octant: its words hold {near plane, far plane} per axis in the
+// order the ray meets them, so there is no min/max per axis, and a NaN distance (ray parallel to the axis: Inf - Inf)
+// only ever lands in the slot where it is ignored.
 __device__ __forceinline__ void node_test(const DevScene& S, const BoxRay& R, float t_min, float t_max, uint32_t node,
                                           bool& hit, uint32_t& link) {
     const uint4 q = S.nodes[node];
     // Box test (src/bounding_box.jl:70-84 form).  It only culls: the stored boxes are rounded strictly outward, and
     // the far distance is widened by 8 ulp so that rounding can never reject a box that the exact slab test of
-    // src/bounding_box.jl:20-67 accepts.  A ray parallel to an axis gives +-Inf on that axis (inside the slab: -Inf and
-    // +Inf); 0 * Inf = NaN would need the origin exactly on a stored plane, outside every box of the reference.
-    const v2f a = (__builtin_convertvector(__builtin_bit_cast(v2h, q.x), v2f) - (v2f){R.o.x, R.o.x}) * (v2f){R.i.x, R.i.x};
-    const v2f b = (__builtin_convertvector(__builtin_bit_cast(v2h, q.y), v2f) - (v2f){R.o.y, R.o.y}) * (v2f){R.i.y, R.i.y};
-    const v2f c = (__builtin_convertvector(__builtin_bit_cast(v2h, q.z), v2f) - (v2f){R.o.z, R.o.z}) * (v2f){R.i.z, R.i.z};
-    float tnear, tfar;
-    if (SORTED) {
-        tnear = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, t_min));
-        tfar = fminf(fminf(a.y, b.y), fminf(c.y, t_max));
-    } else {
-        tnear = fmaxf(fmaxf(fminf(a.x, a.y), fminf(b.x, b.y)), fmaxf(fminf(c.x, c.y), t_min));
-        tfar = fminf(fminf(fmaxf(a.x, a.y), fmaxf(b.x, b.y)), fminf(fmaxf(c.x, c.y), t_max));
-    }
+    // src/bounding_box.jl:20-67 accepts.  A ray parallel to an axis leaves that axis unconstrained (its distances come
+    // out as -Inf / +Inf / NaN, and fmaxf / fminf drop the NaN).
+    const v2h hx = __builtin_bit_cast(v2h, q.x), hy = __builtin_bit_cast(v2h, q.y), hz = __builtin_bit_cast(v2h, q.z);
+    v2f a, b, c; // per axis: distances to the first and the second stored plane (half -> float inside the fused op)
+    a.x = __builtin_fmaf((float)hx.x, R.i.x, R.cn.x); a.y = __builtin_fmaf((float)hx.y, R.i.x, R.cf.x);
+    b.x = __builtin_fmaf((float)hy.x, R.i.y, R.cn.y); b.y = __builtin_fmaf((float)hy.y, R.i.y, R.cf.y);
+    c.x = __builtin_fmaf((float)hz.x, R.i.z, R.cn.z); c.y = __builtin_fmaf((float)hz.y, R.i.z, R.cf.z);
+    float tnear = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, t_min));
+    float tfar = fminf(fminf(a.y, b.y), fminf(c.y, t_max));
     tfar = __builtin_fmaf(fabsf(tfar), 4.8e-7f, tfar);
     hit = tnear <= tfar;
     link = q.w;
 }
-template <bool SORTED>
 __device__ __forceinline__ void node_step(const DevScene& S, const BoxRay& R, float t_min, float t_max, uint32_t& node,
                                           uint32_t& leaf) {
     bool hit;
     uint32_t link;
-    node_test<SORTED>(S, R, t_min, t_max, node, hit, link);
+    node_test(S, R, t_min, t_max, node, hit, link);
     const bool is_leaf = (int32_t)link < 0;
     node = (hit || is_leaf) ? node + 1u : link;
     leaf = (hit && is_leaf) ? (link & ~RT_NODE_LEAF) : 0u;
@@ -516,21 +614,20 @@ __device__ __forceinline__ void node_step(const DevScene& S, const BoxRay& R, fl
 __device__ __forceinline__ void media_closest(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max,
                                               const RngKey& key, Closest& best) {
     if (S.medium_size == 0u) return;
-    // always the first layout: the lanes of a wave then meet the same medium in the same step of the loop (the medium
-    // test is long; with per-octant orders half the wave would sit out each of its executions)
-    uint32_t node = S.medium_root;
+    uint32_t node = S.medium_root + layout_base(S, d);
     const uint32_t end = node + S.medium_size;
     BoxRay R;
     box_frame(S, o, d, R);
     if (best.t != INF) t_max = best.t;
     while (node != end) {
         uint32_t leaf;
-        node_step<false>(S, R, t_min, t_max, node, leaf);
+        node_step(S, R, t_min, t_max, node, leaf);
         if (leaf) {
             uint32_t prim = (leaf & RT_LEAF_PRIM_MASK) - 1u;
             uint4 head;
             Geom G;
             load_prim(S, prim, head, G);
+            if (!ref_reaches<true>(S, prim, 0u, o, d, t_min, t_max)) continue;
             float t = medium_t(S, head.x, G.g, o, d, time, t_min, t_max, key);
             consider(best, t_max, t, prim, ((head.x >> 8) << 3) | ((head.x & DP_TYPE_MASK) << 24), head.z);
         }
@@ -551,19 +648,21 @@ __device__ __forceinline__ void walker_step(Walker& W, const DevScene& S, Counte
     if (W.node == W.end && W.ret != RT_NODE_NONE) walker_return(W, S);
     if (W.node != W.end) {
         if (COUNT) cnt.nodes++;
-        node_step<true>(S, W.R, W.t_min, W.t_max, W.node, W.leaf);
+        node_step(S, W.R, W.t_min, W.t_max, W.node, W.leaf);
     }
 }
 
 // One surface leaf for the ray (o, d) of the frame being walked.  A nested tree is entered (returns true, with the
 // new frame in `W`-style arguments handled by the caller); any other primitive is tested against `best`.
+template <bool FLOOR>
 __device__ __forceinline__ void surface_leaf(const float* Tinv, uint32_t prim, const uint4& head, const Geom& G, f3 o, f3 d,
                                              float time, float t_min, float& t_max, uint32_t inst_rank, uint32_t inst_xf,
-                                             Closest& best) {
+                                             Closest& best, float floor_t, uint32_t floor_rank) {
     uint32_t kind = head.x & 15u;
     uint32_t side = 0, xf = inst_xf;
     float t = surface_t(Tinv, kind, kind == DP_TRIANGLE ? 0u : head.x >> 8, G.g, o, d, time, t_min, t_max, side, xf);
-    consider(best, t_max, t, prim, side | (xf << 3) | ((head.x & DP_TYPE_MASK) << 24), head.z + inst_rank);
+    if (FLOOR) consider(best, t_max, t, prim, side | (xf << 3) | ((head.x & DP_TYPE_MASK) << 24), head.z + inst_rank, floor_t, floor_rank);
+    else consider(best, t_max, t, prim, side | (xf << 3) | ((head.x & DP_TYPE_MASK) << 24), head.z + inst_rank);
 }
 
 // The pending leaf primitive.  Call only for lanes with walker_wants_leaf().
@@ -578,6 +677,7 @@ __device__ __forceinline__ void walker_leaf(Walker& W, const DevScene& S, Counte
     if ((head.x & 15u) == DP_INSTANCE) {
         // Transform{BVHTree}: src/transform.jl:104-116 around src/BVH.jl:22-53
         uint32_t field = head.x >> 8;
+        if (!ref_reaches<true>(S, prim, 0u, W.o, W.d, W.t_min, W.t_hi)) return; // the reference culls the whole nested tree
         W.so = W.o; W.sd = W.d;
         W.ret = W.node; W.ret_end = W.end;
         W.inst_rank = head.z;
@@ -592,8 +692,8 @@ __device__ __forceinline__ void walker_leaf(Walker& W, const DevScene& S, Counte
         W.end = W.node + __float_as_uint(G.g[1]);
         return;
     }
-    surface_leaf((const float*)(S.prim_inv + 3u * prim), prim, head, G, W.o, W.d, W.time, W.t_min, W.t_max, W.inst_rank,
-                 W.inst_xf, W.best);
+    surface_leaf<false>((const float*)(S.prim_inv + 3u * prim), prim, head, G, W.o, W.d, W.time, W.t_min, W.t_max, W.inst_rank,
+                        W.inst_xf, W.best, 0.0f, 0u);
 }
 
 // Wave-wide vote: which block should the wave run now?  0 = step, 1 = leaf, 2 = shade, 3 = nothing left.
@@ -611,6 +711,85 @@ __device__ __forceinline__ int wave_vote(bool ws, bool wl, bool wh, const Vote& 
     return 0;
 }
 
+// The pieces of the scene a surface walk needs, as plain values: what surface_again takes instead of the whole record.
+struct WalkScene {
+    const uint4* nodes;
+    const uint4* prims;
+    const float4* prim_box;
+    const float4* prim_inv;
+    const float* xforms;
+    uint32_t n_nodes, surface_root, surface_size;
+    float node_scale, inv_node_scale;
+};
+__device__ __forceinline__ WalkScene walk_scene(const DevScene& S) {
+    return WalkScene{S.nodes, S.prims, S.prim_box, S.prim_inv, S.xforms, S.n_nodes, S.surface_root, S.surface_size,
+                     S.node_scale, S.inv_node_scale};
+}
+// For a ray whose closest surface hit `best` the reference does not reach (ref_reaches; about one ray in a million):
+// the closest hit behind it that the reference does reach, or none.  The lane walks the surface tree again, on its own,
+// leaving out everything up to the hit that failed -- and again, should the next one fail too.  Kept out of line: the
+// callers are tuned for their common path and must not pay registers for this one.
+__device__ __forceinline__ Closest surface_again(WalkScene A, f3 o, f3 d, float time, float t_min, float t_hi, Closest best) {
+    DevScene S = {};
+    S.nodes = A.nodes; S.prims = A.prims; S.prim_box = A.prim_box; S.prim_inv = A.prim_inv; S.xforms = A.xforms;
+    S.n_nodes = A.n_nodes; S.surface_root = A.surface_root; S.surface_size = A.surface_size;
+    S.node_scale = A.node_scale; S.inv_node_scale = A.inv_node_scale;
+    const f3 wo = o, wd = d; // the ray as cast
+    do {
+        const float floor_t = best.t;
+        const uint32_t floor_rank = best.rank;
+        best.t = INF; best.prim = 0xFFFFFFFFu; best.sx = 0u; best.rank = 0u;
+        float t_max = t_hi;
+        o = wo; d = wd;
+        BoxRay R;
+        box_frame(S, o, d, R);
+        uint32_t node = S.surface_root + layout_base(S, d), end = node + S.surface_size;
+        uint32_t ret = RT_NODE_NONE, ret_end = 0u, inst_rank = 0u, inst_xf = 0u;
+        for (;;) {
+            if (node == end) {
+                if (ret == RT_NODE_NONE) break;
+                o = wo; d = wd; // back out of the nested tree
+                box_frame(S, o, d, R);
+                node = ret; end = ret_end;
+                ret = RT_NODE_NONE;
+                inst_rank = 0u; inst_xf = 0u;
+                continue;
+            }
+            uint32_t leaf;
+            node_step(S, R, t_min, t_max, node, leaf);
+            if (leaf == 0u) continue;
+            const uint32_t prim = (leaf & RT_LEAF_PRIM_MASK) - 1u;
+            uint4 hd;
+            Geom G;
+            load_prim(S, prim, hd, G);
+            if (leaf & RT_LEAF_INSTANCE) { // Transform{BVHTree}: src/transform.jl:104-116 around src/BVH.jl:22-53
+                if (!ref_reaches<true>(S, prim, 0u, o, d, t_min, t_hi)) continue;
+                const uint32_t field = hd.x >> 8;
+                ret = node; ret_end = end;
+                inst_rank = hd.z;
+                inst_xf = field;
+                if (field) {
+                    const float* T = S.xforms + 24u * (field - 1u) + 12;
+                    f3 no = apply_point(T, o), nd = apply_vec(T, d);
+                    o = no; d = nd;
+                }
+                box_frame(S, o, d, R);
+                node = __float_as_uint(G.g[0]) + layout_base(S, d);
+                end = node + __float_as_uint(G.g[1]);
+            } else {
+                surface_leaf<true>((const float*)(S.prim_inv + 3u * prim), prim, hd, G, o, d, time, t_min, t_max, inst_rank, inst_xf,
+                                   best, floor_t, floor_rank);
+            }
+        }
+    } while (best.t != INF && !ref_reaches<false>(S, best.prim, (best.sx >> 3) & 0x3FFFFFFu, wo, wd, t_min, t_hi));
+    return best;
+}
+// `best` as the reference would have it: unchanged if the reference reaches that hit (or there is none)
+__device__ __forceinline__ void settle_surface(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_hi, Closest& best) {
+    if (best.t != INF && !ref_reaches<false>(S, best.prim, (best.sx >> 3) & 0x3FFFFFFu, o, d, t_min, t_hi))
+        best = surface_again(walk_scene(S), o, d, time, t_min, t_hi, best);
+}
+
 // closest hit of one ray per lane (used by the ray parity hook)
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max,
@@ -626,7 +805,10 @@ __device__ __forceinline__ void closest_hit(const DevScene& S, f3 o, f3 d, float
         else { if (wl) walker_leaf<COUNT>(W, S, cnt); }
     }
     best = W.best;
-    if (active) media_closest(S, o, d, time, t_min, t_max, key, best);
+    if (active) {
+        settle_surface(S, o, d, time, t_min, t_max, best);
+        media_closest(S, o, d, time, t_min, t_max, key, best);
+    }
 }
 
 // ------------------------------------------------------------------ hit completion (only for the winner)
@@ -937,8 +1119,9 @@ __device__ __forceinline__ void camera_ray(const RtCameraDev& cam, const float* 
 // rt_sum_kernel then adds each pixel's radiances in column order, the order of the sample loop of draw!
 // (src/Ray_Tracing.jl:82-89), so the image does not depend on scheduling.
 // plane 0: {origin, time}        plane 1: {direction, bits(depth | flag)}   depth == 0: the slot holds no ray
-// plane 2: {acc, bits(pixel)}        plane 3: {t, bits(prim), bits(side|xform), bits(type)}   type: 1..5 material type of
-// the hit, 6 = miss.   plane 4: {color, -}, only valid (and only touched) when DEPTH_HAS_COLOR is set in the depth word
+// plane 2: {acc, bits(pixel)}        plane 3: {t, bits(prim), bits(side|xform|type), bits(rank)}: the closest hit of the
+// device tree, t = Inf: none.   plane 4: {color, -}, only valid (and only touched) when DEPTH_HAS_COLOR is set in the depth word
+// Material types travel as 1..5, HIT_MISS = nothing was hit.
 // Path dispensers (words of the sync array): counter c hands out local indices v; units of DISP_UNIT consecutive paths
 // are dealt round-robin to the counters, so every counter covers the whole batch evenly.
 #define DISP_BASE RT_DISP_BASE
@@ -949,8 +1132,11 @@ __device__ __forceinline__ void camera_ray(const RtCameraDev& cam, const float* 
 #define DEPTH_COLUMN_SHIFT 6
 #define DEPTH_COLUMN_MASK 0xFFFFFFu
 #define DEPTH_HAS_COLOR 0x40000000u
+#define DEPTH_HOLD 0x80000000u       // the slot's hit is being settled (rt_redo_kernel): rt_extend_kernel leaves the slot alone
 #define QP(pool, plane, slot) (pool).q[(size_t)(plane) * (pool).n_slots + (slot)]
 #define HIT_MISS 6u
+#define HIT_WAIT 7u                  // shade kernel: the slot waits for rt_redo_kernel, nothing to shade yet
+#define RANK_SETTLED 0xFFFFFFFFu     // rank word of a hit record that rt_redo_kernel has settled
 #define EXTEND_CHUNK 256u
 
 // random-number key of the path at pixel r (row-major) and column kk of the batch; returns the pattern column
@@ -1050,9 +1236,9 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
         // ---- retire finished rays and fetch new ones once enough lanes are idle
         if ((n_need >= P.fetch_threshold && !exhausted) || (nl | ns) == 0u) {
             if (COUNT) cnt.bounce_waves += first_active_lane();
-            if (fin) { // publish the hit for the shade kernel
-                uint32_t type = best.t != INF ? best.sx >> 29 : HIT_MISS;
-                QP(pool, 3, slot) = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(type));
+            if (fin) {
+                // publish the hit for the shade kernel (the material type is bits 29-31 of sx)
+                QP(pool, 3, slot) = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(best.rank));
                 if (COUNT) cnt.rays++;
                 busy = false;
             }
@@ -1090,7 +1276,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                         if (sidx < cur_end) {
                             float4 p1 = QP(pool, 1, sidx), p0 = QP(pool, 0, sidx);
                             asm volatile("" : "+v"(p0.x), "+v"(p1.x)); // both loads in flight before the depth is looked at
-                            if ((__float_as_uint(p1.w) & DEPTH_MASK) != 0u) {
+                            if (((__float_as_uint(p1.w) & (DEPTH_MASK | DEPTH_HOLD)) - 1u) < DEPTH_MASK) { // holds a ray, not on hold
                                 slot = sidx;
                                 busy = true;
                                 o = mk3(p0.x, p0.y, p0.z); d = mk3(p1.x, p1.y, p1.z);
@@ -1134,6 +1320,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                     // Transform{BVHTree}: src/transform.jl:104-116 around src/BVH.jl:22-53.  The flagged entry is
                     // the last one a lane queues, so the queue is empty now.
                     uint32_t field = hd.x >> 8;
+                    if (!ref_reaches<true>(S, prim, 0u, o, d, t_min, INF)) continue; // the reference culls the whole nested tree
                     so = o; sd = d;
                     ret = node; ret_end = end;
                     inst_rank = hd.z;
@@ -1147,7 +1334,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                     node = __float_as_uint(G.g[0]) + layout_base(S, d);
                     end = node + __float_as_uint(G.g[1]);
                 } else {
-                    surface_leaf(Tinv, prim, hd, G, o, d, time, t_min, t_max, inst_rank, inst_xf, best);
+                    surface_leaf<false>(Tinv, prim, hd, G, o, d, time, t_min, t_max, inst_rank, inst_xf, best, 0.0f, 0u);
                 }
             }
             continue;
@@ -1162,7 +1349,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                     if (COUNT) { cnt.nodes++; cnt.node_waves += first_active_lane(); }
                     bool hit;
                     uint32_t link;
-                    node_test<true>(S, R, t_min, t_max, node, hit, link);
+                    node_test(S, R, t_min, t_max, node, hit, link);
                     // branch-free bookkeeping: where the walk goes on, and the leaf queue (a shift register)
                     const bool is_leaf = (int32_t)link < 0;
                     const bool push = hit && is_leaf;
@@ -1183,6 +1370,32 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
         atomicAdd(&counters[3], (unsigned long long)cnt.node_waves);
         atomicAdd(&counters[4], (unsigned long long)cnt.prim_waves);
         atomicAdd(&counters[5], (unsigned long long)cnt.bounce_waves);
+    }
+}
+
+// The slots that rt_shade_kernel put on hold: the closest surface rt_extend_kernel found for their ray is one the
+// reference does not reach (ref_reaches).  Each ray is walked again for the closest hit behind that one which the
+// reference does reach (surface_again); the hit record is marked settled, and the next rt_shade_kernel shades it.
+// Runs once per batch of bounces: a slot may wait a few launches, which changes nothing for its path.
+// sync[RT_REDO_COUNT]: number of entries in pool.redo, reset by the last workgroup to finish (sync[RT_REDO_COUNT + 1]
+// counts the finished ones).
+__global__ void __launch_bounds__(256) rt_redo_kernel(DevScene S, PathPool pool, uint32_t* __restrict__ sync) {
+    const uint32_t n = __hip_atomic_load(sync + RT_REDO_COUNT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t slot = pool.redo[i];
+        const float4 p0 = QP(pool, 0, slot), p1 = QP(pool, 1, slot), h = QP(pool, 3, slot);
+        Closest best;
+        best.t = h.x; best.prim = __float_as_uint(h.y); best.sx = __float_as_uint(h.z); best.rank = __float_as_uint(h.w);
+        best = surface_again(walk_scene(S), mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), p0.w, 0.001f, INF, best);
+        QP(pool, 3, slot) = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(RANK_SETTLED));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u && n != 0u) {
+        __threadfence();
+        if (atomicAdd(sync + RT_REDO_COUNT + 1u, 1u) == gridDim.x - 1u) {
+            sync[RT_REDO_COUNT] = 0u;
+            sync[RT_REDO_COUNT + 1u] = 0u;
+        }
     }
 }
 
@@ -1210,17 +1423,31 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
         float4 q1 = QP(pool, 1, base + t), q2 = QP(pool, 2, base + t), q4 = QP(pool, 3, base + t);
         int depth0 = (int)(__float_as_uint(q1.w) & DEPTH_MASK);
         if (depth0 > 0) {
-            if (S.medium_size != 0u) {
-                RngKey key;
-                path_key(P, (__float_as_uint(q1.w) >> DEPTH_COLUMN_SHIFT) & DEPTH_COLUMN_MASK, __float_as_uint(q2.w), key);
-                float4 q0 = QP(pool, 0, base + t);
-                key.bounce = (uint32_t)(P.max_depth - depth0);
-                Closest best;
-                best.t = q4.x; best.prim = __float_as_uint(q4.y); best.sx = __float_as_uint(q4.z); best.rank = 0u;
-                uint32_t surface = best.prim;
-                media_closest(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, 0.001f, INF, key, best);
-                if (best.prim != surface)
-                    q4 = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(best.sx >> 29));
+            const float4 q0 = QP(pool, 0, base + t);
+            const f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q1.x, q1.y, q1.z);
+            // rt_extend_kernel found the closest surface of the device tree.  Here, with every lane holding a ray, that
+            // hit is held against the boxes of the reference's trees (ref_reaches).  In the rare case that it does not
+            // stand the slot is put on hold: rt_redo_kernel finds the hit that does, and the slot is shaded a few
+            // launches later.
+            Closest best;
+            best.t = q4.x; best.prim = __float_as_uint(q4.y); best.sx = __float_as_uint(q4.z); best.rank = 0u;
+            const bool held = (__float_as_uint(q1.w) & DEPTH_HOLD) != 0u;
+            if (held && __float_as_uint(q4.w) != RANK_SETTLED) {
+                q4.w = __uint_as_float(HIT_WAIT); // still waiting for rt_redo_kernel
+            } else if (!held && best.t != INF && !ref_reaches<false>(S, best.prim, (best.sx >> 3) & 0x3FFFFFFu, o, d, 0.001f, INF)) {
+                // plane 3 keeps {t, prim, sx, rank} of the hit that does not stand: where the redo starts from
+                reinterpret_cast<uint32_t*>(&QP(pool, 1, base + t))[3] = __float_as_uint(q1.w) | DEPTH_HOLD;
+                pool.redo[atomicAdd(sync + RT_REDO_COUNT, 1u)] = base + t;
+                q4.w = __uint_as_float(HIT_WAIT);
+            } else {
+                if (S.medium_size != 0u) {
+                    RngKey key;
+                    path_key(P, (__float_as_uint(q1.w) >> DEPTH_COLUMN_SHIFT) & DEPTH_COLUMN_MASK, __float_as_uint(q2.w), key);
+                    key.bounce = (uint32_t)(P.max_depth - depth0);
+                    media_closest(S, o, d, q0.w, 0.001f, INF, key, best);
+                }
+                q4 = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx),
+                                 __uint_as_float(best.t != INF ? best.sx >> 29 : HIT_MISS));
             }
             hits[t] = q4;
             my_key = __float_as_uint(q4.w) & 7u;
@@ -1250,7 +1477,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
     const uint32_t depth_word = __float_as_uint(q1.w);
     int depth = (int)(depth_word & DEPTH_MASK);
     bool done = false, cont = false;
-    if (valid && depth > 0) {
+    if (valid && depth > 0 && (__float_as_uint(hits[mine].w) & 7u) == HIT_WAIT) {
+        cont = true; // on hold: the slot keeps its ray
+    } else if (valid && depth > 0) {
         float4 q4 = hits[mine];
         const uint32_t kk = (depth_word >> DEPTH_COLUMN_SHIFT) & DEPTH_COLUMN_MASK, r = __float_as_uint(q2.w);
         RngKey key;
@@ -1436,6 +1665,7 @@ __global__ void __launch_bounds__(256) rt_trace_paths_kernel(DevScene S, RtCamer
             f3 no, nd;
             if (done) c = ps.color;
             else {
+                settle_surface(S, W.o, W.d, W.time, 0.001f, INF, W.best);
                 media_closest(S, W.o, W.d, W.time, 0.001f, INF, key, W.best);
                 done = shade<true>(S, W.o, W.d, W.time, W.best, ps, bgc, key, c, no, nd);
             }
@@ -1470,6 +1700,9 @@ extern "C" void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, cons
     else hipLaunchKernelGGL(rt_shade_kernel<false>, dim3(shade_blocks), dim3(SHADE_BLOCK), 0, stream, *S, *cam, d_pattern, *P, *pool,
                             d_radiance, d_sync, d_active);
     if (timing) (void)hipEventRecord(timing[2], stream);
+}
+extern "C" void rt_launch_redo(const DevScene* S, const PathPool* pool, uint32_t* d_sync, hipStream_t stream) {
+    hipLaunchKernelGGL(rt_redo_kernel, dim3(256), dim3(256), 0, stream, *S, *pool, d_sync);
 }
 extern "C" void rt_launch_sum(const RtRenderParams* P, const float4* d_radiance, float* d_accum, int first_batch, hipStream_t stream) {
     hipLaunchKernelGGL(rt_sum_kernel, dim3((P->n_pixels + 255u) / 256u), dim3(256), 0, stream, *P, d_radiance, d_accum, first_batch);

@@ -124,7 +124,26 @@ struct Builder {
         float m[12] = {0};
         if (field && kind != DP_TRIANGLE) std::memcpy(m, &H.xforms[24 * (size_t)(field - 1) + 12], sizeof(m));
         for (int k = 0; k < 3; ++k) H.prim_inv.push_back(make_float4(m[4 * k], m[4 * k + 1], m[4 * k + 2], m[4 * k + 3]));
+        for (int k = 0; k < 4; ++k) H.prim_box.push_back(make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         return idx;
+    }
+    // The boxes the reference tests before it reaches the primitive (src/BVH.jl:22-53, src/mesh.jl:115-163): only the
+    // leaf's own box matters, every box above it contains it and is tested with the same ray and the same arithmetic.
+    // outer: leaf box in the top-level tree, ray as cast; inner: leaf box inside a nested tree, ray in that tree's frame.
+    void set_ref_boxes(uint32_t prim, const float* outer, const float* inner) {
+        float4* b = &H.prim_box[4 * (size_t)prim];
+        uint32_t flags = 0;
+        if (outer) {
+            b[0] = make_float4(outer[0], outer[1], outer[2], outer[3]);
+            b[1].x = outer[4]; b[1].y = outer[5];
+            flags |= RT_BOX_OUTER;
+        }
+        if (inner) {
+            b[2] = make_float4(inner[0], inner[1], inner[2], inner[3]);
+            b[3] = make_float4(inner[4], inner[5], 0.0f, 0.0f);
+            flags |= RT_BOX_INNER;
+        }
+        b[1].z = bitsf(flags);
     }
 
     bool valid_obj(int oi) { return oi >= 0 && oi < D.n_objects; }
@@ -333,6 +352,7 @@ struct Builder {
             if (!make_prim(oi, rank, top, nested ? oi : 0, nested, inl ? inl->xf : 0u, prim)) return false;
             uint32_t head = H.prims[3 * (size_t)prim].x;
             bool instance = (head & 15u) == DP_INSTANCE;
+            set_ref_boxes(prim, nested ? (inl ? inl->clip_box : nullptr) : leaf_box, nested ? leaf_box : nullptr);
             float world_box[6];
             if (inl) { // the object-frame box of the leaf, as a world-frame box inside the box of the whole nested tree
                 double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -461,6 +481,7 @@ struct Builder {
                 float pad = 1e-4f * ext + 4e-6f * mag;
                 // never larger than the box the reference walks for this triangle (the leaf's box)
                 const float* lb = T.node_bounds + 6 * (size_t)(id - 1);
+                set_ref_boxes(prim, lb, nullptr);
                 for (int ax = 0; ax < 3; ++ax) {
                     box[ax] = std::max(box[ax] - pad, std::min(lb[ax], box[ax]));
                     box[3 + ax] = std::min(box[3 + ax] + pad, std::max(lb[3 + ax], box[3 + ax]));

@@ -17,6 +17,7 @@ struct HostScene {
     bool textured = false; // a texture other than SolidColor present
     std::vector<uint4> prims;  // 3 per primitive
     std::vector<float4> prim_inv; // 3 per primitive
+    std::vector<float4> prim_box; // 4 per primitive
     std::vector<float> xforms; // 24 per transform
     std::vector<uint4> materials;
     std::vector<uint4> textures; // 2 per texture

@@ -58,6 +58,8 @@ def lib():
                                  C.c_int, C.c_int, C.c_uint64, C.c_int, ffi.c_f32p, C.POINTER(refStats)]
         L.ref_trace_paths.argtypes = [C.c_void_p, C.POINTER(ffi.rtCamera), ffi.c_f32p, C.c_int, ffi.c_f32p, C.c_int,
                                       C.c_int, C.c_int, C.c_uint64, ffi.c_i32p, C.c_int, ffi.c_f32p]
+        L.ref_path_rays.argtypes = [C.c_void_p, C.POINTER(ffi.rtCamera), ffi.c_f32p, C.c_int, ffi.c_f32p, C.c_int,
+                                    C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, ffi.c_f32p, C.c_int]
         L.ref_trace_rays.argtypes = [C.c_void_p, ffi.c_f32p, C.c_int, C.c_float, C.c_float, C.c_uint64, ffi.c_i32p,
                                      ffi.c_i32p, ffi.c_f32p, ffi.c_f32p, ffi.c_f32p, ffi.c_u8p]
         L.ref_bucket_count.argtypes = [C.c_void_p]
@@ -135,6 +137,18 @@ class OracleScene:
         _check(lib().ref_trace_paths(self.handle, C.byref(cam), ffi.fptr(pat), n, ffi.fptr(bg), width, height,
                                      max_depth, seed, ffi.iptr(ids), ids.shape[0], ffi.fptr(rad)))
         return rad
+
+    def path_rays(self, camera, pattern, background, width, height, i, j, s, max_depth=50, seed=0x5EED):
+        """The rays path (i, j, s) casts, one row of 7 floats per bounce."""
+        pat, n = _pattern(pattern)
+        bg = np.asarray(background, dtype=F)
+        rays = np.zeros((max_depth, 7), dtype=F)
+        cam = camera_record(camera)
+        m = lib().ref_path_rays(self.handle, C.byref(cam), ffi.fptr(pat), n, ffi.fptr(bg), width, height, max_depth,
+                                seed, i, j, s, ffi.fptr(rays), max_depth)
+        if m < 0:
+            _check(m)
+        return rays[:m].copy()
 
     def trace_rays(self, rays, t_min=0.001, t_max=np.inf, seed=0x5EED):
         rays = np.ascontiguousarray(rays, dtype=F).reshape(-1, 7)

@@ -100,24 +100,28 @@ def test_structure_and_coverage(name, layouts):
 def walk(nodes, info, octant, root, size, o, d, t_min=0.001):
     """the stackless walk of rt_kernels.hip for one ray, in float32 like the kernel (exact division instead of the
     hardware reciprocal): the layout of the ray's octant stores every axis as (near plane, far plane), so the entry
-    distance is the largest of the first halves and the exit distance the smallest of the second halves.  Returns the
+    distance is the largest of the first halves and the exit distance the smallest of the second halves; a plane
+    distance is plane * (1/d) - origin * (1/d) fused, with the rounding slack of the second product moved outward.  Returns the
     list of leaf words visited with the box passed."""
     N = info.nodes_per_layout
     F = np.float32
     scale = F(info.node_scale)
-    os_ = (o * scale).astype(F)
-    with np.errstate(divide="ignore"):
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         inv = (F(1) / d).astype(F) * (F(1) / scale)
+        oi = ((o * scale).astype(F) * inv).astype(F)
+        slack = (np.abs(oi) * F(2.0 ** -22)).astype(F)
+        cn, cf = (-oi - slack).astype(F), (-oi + slack).astype(F)
     link = nodes[octant, :, 3]
-    planes = nodes[octant, :, :3].copy().view(np.float16).astype(np.float32)     # x near, x far, y near, y far, z near, z far
+    planes = nodes[octant, :, :3].copy().view(np.float16).astype(np.float64)     # x near, x far, y near, y far, z near, z far
     node = octant * N + root
     end = node + size
     out = []
     while node != end:
         i = node - octant * N
-        with np.errstate(invalid="ignore"):
-            t0 = (planes[i, 0::2] - os_) * inv
-            t1 = (planes[i, 1::2] - os_) * inv
+        with np.errstate(invalid="ignore", over="ignore"):
+            # plane * inv + c, fused (one rounding): the product of a half and a float is exact in float64
+            t0 = (planes[i, 0::2] * inv.astype(np.float64) + cn.astype(np.float64)).astype(F)
+            t1 = (planes[i, 1::2] * inv.astype(np.float64) + cf.astype(np.float64)).astype(F)
         tnear = max(np.fmax.reduce(t0), F(t_min))
         tfar = np.fmin.reduce(t1)
         with np.errstate(invalid="ignore"):

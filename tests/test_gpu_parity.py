@@ -187,10 +187,53 @@ def test_degenerate_rays_terminate_and_match(name, scenes):
         rays.append(np.concatenate([o, np.asarray(d, F), [0.5]]))
     for oo in ([np.nan, 0, 0], [np.inf, 0, 0], [1e30, -1e30, 0], [0, 0, 0]):
         rays.append(np.concatenate([np.asarray(oo, F), base[5, 3:6], [0.5]]))
+    # nearly axis-parallel rays (huge reciprocals: the rounding slack of the box test is largest here) from the camera
+    # and from points inside the scene, and rays that start on a coordinate plane (origin component exactly 0)
+    rng = np.random.default_rng(11)
+    centre = base[:, :3].mean(axis=0) + base[:, 3:6].mean(axis=0)
+    for k in range(400):
+        src = base[rng.integers(len(base))]
+        oo = src[:3].copy() if k % 2 else (src[:3] + src[3:6] * F(rng.uniform(0.2, 1.5))).astype(F)
+        d = (centre - oo + rng.normal(0, 1, 3) * np.abs(centre - oo).max()).astype(F) if k % 2 == 0 else src[3:6].copy()
+        for axis in rng.choice(3, size=rng.integers(1, 3), replace=False):
+            d[axis] *= F(10.0) ** F(-rng.integers(4, 40))
+        if k % 7 == 0:
+            oo[rng.integers(3)] = 0.0
+        rays.append(np.concatenate([oo, d, [rng.uniform()]]))
     rays = np.asarray(rays, F)
     a, b = ref.trace_rays(rays), dev.trace_rays(rays)
     np.testing.assert_array_equal(a["prim_id"], b["prim_id"])
     np.testing.assert_array_equal(bits(a["t"]), bits(b["t"]))
+    assert (a["prim_id"] >= 0).sum() > 40
+
+
+def test_boxes_the_reference_culls():
+    """The reference tests the box of a leaf before the primitive in it (src/bounding_box.jl:20-67, `t_max <= t_min`
+    rejects).  A rectangle's box is 0.0002 thick: seen from 60000 away its two plane distances round to the same float
+    and the reference never reaches the rectangle.  The Cornell box from that distance: the back wall (z = 555) is gone
+    for every camera ray, the sphere behind it shows, and inside the box the paths go on as usual.  Same rays, same
+    image as the oracle, although every primary hit on the back wall has to be walked again on the device."""
+    from raytracing_amd.hittables import Camera, Emissive, Lambertian, Material, Sphere, Vec3
+    world, kw = rt.get_scene("cornell_box", spp=1)
+    bg = kw["background"]
+    world = list(world) + [Sphere(Vec3(278, 278, 1500), 700, Material(Emissive, Vec3(0.5, 0.7, 0.9))),
+                           Sphere(Vec3(278, 278, -20000), 60, Material(Lambertian, Vec3(0.3, 0.3, 0.8)))]
+    origin = Vec3(278, 278, -60000)
+    cam = Camera(origin, origin - Vec3(278, 278, 0), Vec3(0, 1, 0), 0.57, 1.0, 0.0, 10.0, 0.0, 1.0)
+    ref, dev = O.OracleScene(world), rt.DeviceScene(world)
+    try:
+        rays = O.primary_rays(cam, 96, 96, 96, 96)
+        a, b = ref.trace_rays(rays), dev.trace_rays(rays)
+        np.testing.assert_array_equal(a["prim_id"], b["prim_id"])
+        np.testing.assert_array_equal(bits(a["t"]), bits(b["t"]))
+        assert (a["prim_id"] == 5).sum() == 0 and (a["prim_id"] == 8).sum() > 1000   # no back wall; the sphere behind it
+        assert (a["prim_id"] == 3).sum() > 20                                        # the floor is still there
+        pat = rt.Halton_sequence32(6)
+        img, st = dev.render(cam, pat, bg, 96, 96)
+        np.testing.assert_array_equal(bits(img), bits(ref.render(cam, pat, bg, 96, 96)))
+        assert st.paths == 96 * 96 * 6 and img.max() > 0.5
+    finally:
+        dev.close()
 
 
 def test_nested_tree_kept_as_instance(scenes, monkeypatch):

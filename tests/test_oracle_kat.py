@@ -131,6 +131,21 @@ def test_rect_hits_and_closed_bounds():
     np.testing.assert_array_equal(h["uv"], [0.5, 0.25])
 
 
+# ------------------------------------------------------------------ src/bounding_box.jl:20-67 in front of src/aarect.jl:49-95
+def test_leaf_box_is_tested_before_the_primitive():
+    """The tree tests the box of a leaf first and turns it down when `t_max <= t_min` after any axis.  A rectangle's
+    box is its plane +- 0.0001: from far enough away the two plane distances round to one float, and the rectangle is
+    never reached although its own hit function would accept the ray."""
+    r = xy_rect(-10, 10, -10, 10, 3, white)
+    assert hit1([r], (0, 0, -1000), (0, 0, 1))["t"] == F(1003)          # ulp(1003) = 6.1e-5 < 0.0002: two distances
+    assert hit1([r], (0, 0, -5000), (0, 0, 1))["prim_id"] == -1         # ulp(5003) = 4.9e-4: both planes at one distance
+    # a ray inside the plane of a box face: 0 * Inf = NaN on that axis is ignored, the other axes decide
+    b = Box(Vec3(0, 0, 0), Vec3(2, 2, 2), white)
+    assert hit1([b], (-1, 1, 2), (1, 0, 0))["t"] == F(1)
+    # ... also when the primitive only touches that plane (tangent ray along the top of a sphere's box)
+    assert hit1([Sphere(Vec3(0, 0, 0), 1, white)], (-5, 1, 0), (1, 0, 0))["t"] == F(5)
+
+
 # ------------------------------------------------------------------ src/box.jl:9-24,43-83
 def test_box_sides_in_reference_order():
     b = Box(Vec3(0, 0, 0), Vec3(1, 2, 3), white)
@@ -262,6 +277,24 @@ def test_trace_emission_background_and_depth():
     # depth 2: mirror -> miss -> albedo * background
     grey = Material(Metal, Vec3(0.5, 0.25, 1.0), 0.0)
     np.testing.assert_array_equal(_radiance([xy_rect(-1e4, 1e4, -1e4, 1e4, -10, grey)], Vec3(1), ids, max_depth=2)[0], [0.5, 0.25, 1.0])
+
+
+def test_path_rays_lists_the_rays_of_trace():
+    """path_rays: the camera ray and every scattered ray of one path, in order (src/Ray_Tracing.jl:11-29)"""
+    mirror = Material(Metal, Vec3(1, 1, 1), 0.0)
+    mirrors = [xy_rect(-1e4, 1e4, -1e4, 1e4, -10, mirror), xy_rect(-1e4, 1e4, -1e4, 1e4, 10, mirror)]
+    S = O.OracleScene(mirrors)
+    cam, pat = _camera(), np.zeros((2, 1), F)
+    rays = S.path_rays(cam, pat, Vec3(0), 4, 4, 1, 2, 0, max_depth=7)
+    assert rays.shape == (7, 7)                                            # depth 7: seven rays, all of them hit
+    np.testing.assert_array_equal(rays[0, :3], np.asarray(cam.origin, F))
+    h = S.trace_rays(rays)
+    assert (h["prim_id"] >= 0).all()
+    for k in range(6):  # each ray starts where the one before it ended, reflected about z
+        p = rays[k, :3] + h["t"][k] * rays[k, 3:6]
+        np.testing.assert_allclose(rays[k + 1, :3], p, rtol=1e-6, atol=1e-6)
+        assert np.sign(rays[k + 1, 5]) == -np.sign(rays[k, 5])
+    assert S.path_rays(cam, pat, Vec3(0), 4, 4, 1, 2, 0, max_depth=0).shape == (0, 7)
 
 
 def test_image_texture_lookup_quirks():
