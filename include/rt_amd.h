@@ -244,7 +244,7 @@ void rt_obj_free(rtObjMesh* mesh);
 /* Test hook without a counterpart in the reference: the acceleration structure the library builds for a scene
  * (its own SAH trees in eight ray-octant layouts, see raytracing_amd/csrc/rt_device.h), computed on the host without
  * a GPU, so that its invariants (every primitive once per layout, links in range, boxes that enclose the reference's
- * boxes, conservative culling) can be checked anywhere.  `nodes` receives 4 words per node for 8 * nodes_per_layout
+ * boxes, conservative culling) can be checked anywhere.  `nodes` receives 4 words per node for n_sets * 8 * nodes_per_layout
  * nodes and `prim_top` the position in the world vector of every primitive; either may be NULL, and a call with too
  * little capacity only fills `info` (and returns RT_OK), so a first call sizes the buffers. */
 typedef struct rtLayout {
@@ -252,6 +252,8 @@ typedef struct rtLayout {
     uint32_t surface_root, surface_size, medium_root, medium_size; /* layout-relative roots, node counts */
     uint32_t nested;    /* 1 if nested trees follow the two main trees */
     float node_scale;   /* power of two the stored boxes were multiplied by */
+    uint32_t n_sets;    /* node sets (8 layouts each): 1, or 2 = {tight boxes, the reference's boxes} */
+    float centre[3], radius; /* rays that start inside this ball walk set 0, all others the last set */
 } rtLayout;
 int rt_scene_layout(const rtSceneDesc* desc, rtLayout* info, uint32_t* nodes, size_t node_capacity,
                     int32_t* prim_top, size_t prim_capacity);

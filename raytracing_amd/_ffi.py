@@ -92,7 +92,8 @@ class rtStats(C.Structure):
 class rtLayout(C.Structure):
     _fields_ = [("nodes_per_layout", C.c_uint32), ("n_prims", C.c_uint32), ("surface_root", C.c_uint32),
                 ("surface_size", C.c_uint32), ("medium_root", C.c_uint32), ("medium_size", C.c_uint32),
-                ("nested", C.c_uint32), ("node_scale", C.c_float)]
+                ("nested", C.c_uint32), ("node_scale", C.c_float), ("n_sets", C.c_uint32), ("centre", C.c_float * 3),
+                ("radius", C.c_float)]
 
 
 class rtObjMesh(C.Structure):

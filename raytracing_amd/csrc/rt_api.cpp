@@ -36,6 +36,8 @@ int rt_fail(int status, const char* fmt, ...) {
 struct rtScene {
     int device = 0;
     DevScene dev{};
+    HostScene host;              // the staged scene: its leaves and tables stay, for node sets built for a wider reach
+    uint4* d_nodes = nullptr;    // room for two node sets
     void* buffers[16] = {nullptr};
     int n_buffers = 0;
     // scratch owned by the handle, grown on demand
@@ -66,6 +68,36 @@ int env_int(const char* name, int fallback) {
     return v && std::atoi(v) > 0 ? std::atoi(v) : fallback;
 }
 
+// the node sets of s->host into d_nodes (allocated once, for two sets) and what the kernels need to know about them
+int upload_nodes(rtScene* s) {
+    const HostScene& H = s->host;
+    const size_t capacity = (size_t)16 * H.nodes_per_layout;
+    if (H.nodes.size() != (size_t)H.n_sets * 8u * H.nodes_per_layout || H.nodes.size() > capacity)
+        return rt_fail(RT_EINVAL, "internal: node sets of unexpected size");
+    if (!s->d_nodes) HIP_TRY(hipMalloc((void**)&s->d_nodes, capacity ? capacity * sizeof(uint4) : 16));
+    if (!H.nodes.empty()) HIP_TRY(hipMemcpy(s->d_nodes, H.nodes.data(), H.nodes.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    s->dev.nodes = s->d_nodes;
+    s->dev.n_nodes = H.nodes_per_layout;
+    s->dev.far_set = H.n_sets == 2 ? 8u * H.nodes_per_layout : 0u;
+    for (int i = 0; i < 3; ++i) s->dev.centre[i] = H.centre[i];
+    s->dev.radius2 = H.radius * H.radius;
+    return RT_OK;
+}
+
+// Makes sure the node boxes hold for rays that start up to `needed` from the origin (|coordinate|): the boxes of
+// objects taken out of nested trees are padded in proportion to that (rt_build_nodes).  Scenes are built for rays that
+// start inside them; a camera far outside asks for more, and a later call from close by gets the tighter boxes back.
+int ensure_reach(rtScene* s, double needed) {
+    HostScene& H = s->host;
+    if (!(needed >= 0.0) || !std::isfinite(needed)) needed = 0.0;
+    const double target = 2.0 * std::max(needed, H.scene_reach);
+    if (H.reach >= needed && H.reach <= 64.0 * target) return RT_OK;
+    if (s->last_stream) HIP_TRY(hipStreamSynchronize(s->last_stream));
+    HIP_TRY(hipDeviceSynchronize());
+    rt_build_nodes(&H, target);
+    return upload_nodes(s);
+}
+
 template <typename T>
 int upload(rtScene* s, const std::vector<T>& v, const T** out) {
     *out = nullptr;
@@ -85,6 +117,16 @@ int ensure(T** buf, size_t* cap, size_t count) {
     HIP_TRY(hipMalloc((void**)buf, count * sizeof(T)));
     *cap = count;
     return RT_OK;
+}
+
+// largest |coordinate| a camera ray can start from (src/camera.jl:38-42: origin + lens_radius * (u, v combination))
+double camera_reach(const rtCamera* c) {
+    double m = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        const double v = std::fabs((double)c->origin[i]) + std::fabs((double)c->lens_radius) * (std::fabs((double)c->u[i]) + std::fabs((double)c->v[i]));
+        if (std::isfinite(v)) m = std::max(m, v);
+    }
+    return m;
 }
 
 uint32_t fold_seed(uint64_t seed) { return (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u); }
@@ -135,19 +177,19 @@ int rt_device_count(int* count) {
 int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     if (!desc || !out) return rt_fail(RT_EINVAL, "rt_scene_create: null argument");
     *out = nullptr;
-    HostScene H;
-    int st = rt_flatten_scene(desc, &H);
-    if (st != RT_OK) return st;
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n == 0) return rt_fail(RT_ENODEV, "no HIP device available (%s)", hipGetErrorString(e));
-    if (device < 0 || device >= n) return rt_fail(RT_EINVAL, "device %d out of range (0..%d)", device, n - 1);
-    HIP_TRY(hipSetDevice(device));
     rtScene* s = new (std::nothrow) rtScene();
     if (!s) return rt_fail(RT_ENOMEM, "out of host memory");
+    HostScene& H = s->host;
+    int st = rt_flatten_scene(desc, &H);
+    if (st != RT_OK) { delete s; return st; }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) { delete s; return rt_fail(RT_ENODEV, "no HIP device available (%s)", hipGetErrorString(e)); }
+    if (device < 0 || device >= n) { delete s; return rt_fail(RT_EINVAL, "device %d out of range (0..%d)", device, n - 1); }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) { delete s; return rt_fail(RT_EHIP, "hipSetDevice failed: %s", hipGetErrorString(e)); }
     s->device = device;
-    st = RT_OK;
-    if (st == RT_OK) st = upload(s, H.nodes, &s->dev.nodes);
+    st = upload_nodes(s);
     if (st == RT_OK) st = upload(s, H.prims, &s->dev.prims);
     if (st == RT_OK) st = upload(s, H.prim_inv, &s->dev.prim_inv);
     if (st == RT_OK) st = upload(s, H.prim_box, &s->dev.prim_box);
@@ -174,7 +216,6 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
         else s->n_cus = prop.multiProcessorCount;
     }
     if (st != RT_OK) { rt_scene_destroy(s); return st; }
-    s->dev.n_nodes = H.nodes_per_layout;
     s->dev.node_scale = H.node_scale;
     s->dev.inv_node_scale = 1.0f / H.node_scale;
     s->dev.n_prims = (uint32_t)(H.prims.size() / 3);
@@ -200,6 +241,9 @@ int rt_scene_layout(const rtSceneDesc* desc, rtLayout* info, uint32_t* nodes, si
     info->medium_root = H.medium_root; info->medium_size = H.medium_size;
     info->nested = H.nested ? 1u : 0u;
     info->node_scale = H.node_scale;
+    info->n_sets = H.n_sets;
+    for (int i = 0; i < 3; ++i) info->centre[i] = H.centre[i];
+    info->radius = H.radius;
     if (nodes && node_capacity >= H.nodes.size()) std::memcpy(nodes, H.nodes.data(), H.nodes.size() * sizeof(uint4));
     if (prim_top && prim_capacity >= H.prim_top.size()) std::memcpy(prim_top, H.prim_top.data(), H.prim_top.size() * sizeof(int32_t));
     return RT_OK;
@@ -209,6 +253,7 @@ int rt_scene_destroy(rtScene* s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->device);
     for (int i = 0; i < s->n_buffers; ++i) (void)hipFree(s->buffers[i]);
+    if (s->d_nodes) (void)hipFree(s->d_nodes);
     if (s->d_pattern) (void)hipFree(s->d_pattern);
     if (s->d_radiance) (void)hipFree(s->d_radiance);
     if (s->d_pool) (void)hipFree(s->d_pool);
@@ -236,6 +281,8 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
     if (st != RT_OK) return st;
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(s->device));
+    st = ensure_reach(s, camera_reach(camera));
+    if (st != RT_OK) return st;
     P.sample_first = sample_first;
     P.sample_stride = sample_stride;
     const uint32_t n_shard_samples = (uint32_t)((n - sample_first + sample_stride - 1) / sample_stride);
@@ -415,6 +462,16 @@ int rt_trace_rays(rtScene* s, const float* rays, int n, float t_min, float t_max
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(s->device));
     size_t N = (size_t)n;
+    {
+        double m = 0.0;
+        for (size_t k = 0; k < N; ++k)
+            for (int i = 0; i < 3; ++i) {
+                const double v = std::fabs((double)rays[7 * k + i]);
+                if (std::isfinite(v)) m = std::max(m, v);
+            }
+        int st0 = ensure_reach(s, m);
+        if (st0 != RT_OK) return st0;
+    }
     // one device block: rays(7) prim(1) sub(1) t(1) normal(3) uv(2) as 4-byte words, then the front bytes
     char* d = nullptr;
     size_t words = N * 15;
@@ -457,6 +514,8 @@ int rt_trace_paths(rtScene* s, const rtCamera* camera, const float* pattern, int
         if (ids[3 * k] < 0 || ids[3 * k] >= width || ids[3 * k + 1] < 0 || ids[3 * k + 1] >= height || ids[3 * k + 2] < 0 || ids[3 * k + 2] >= n)
             return rt_fail(RT_EINVAL, "rt_trace_paths: path id %d out of range", k);
     HIP_TRY(hipSetDevice(s->device));
+    st = ensure_reach(s, camera_reach(camera));
+    if (st != RT_OK) return st;
     st = ensure(&s->d_pattern, &s->pattern_cap, (size_t)2 * (size_t)n);
     if (st != RT_OK) return st;
     size_t N = (size_t)n_paths;

@@ -69,6 +69,11 @@ struct DevScene {
     const int32_t* prim_top;     // per primitive: position in the world vector (reported prim_id)
     const int32_t* prim_sub;     // per primitive: reported sub id base (triangle id / nested object index)
     uint32_t n_nodes, n_prims; // n_nodes: nodes per octant layout
+    // Two sets of eight layouts each: the first with tight boxes, for rays that start inside the ball (centre, radius2 =
+    // radius squared), the second -- far_set nodes further on -- with the reference's own boxes, for all other rays.
+    // far_set = 0: one set for every ray.
+    uint32_t far_set;
+    float centre[3], radius2;
     float node_scale, inv_node_scale; // power of two applied to the node boxes (and to the ray for the box test)
     uint32_t surface_root, surface_size; // root of the surface tree (layout-relative) and its node count (0: no surfaces)
     uint32_t nested;       // 1 if the scene holds nested trees (Transform{BVHTree})

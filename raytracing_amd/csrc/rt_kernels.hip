@@ -457,6 +457,7 @@ struct Walker {
     uint32_t leaf;             // pending leaf word: (primitive index + 1) | flags, 0 = none
     Closest best;
     float t_hi;                // t_max the ray was cast with
+    uint32_t set;              // node_set() of the ray
 };
 
 // first node of the layout that orders children near side first for direction d (one layout per octant)
@@ -465,13 +466,21 @@ __device__ __forceinline__ uint32_t layout_base(const DevScene& S, f3 d) {
     uint32_t octant = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
     return octant * S.n_nodes;
 }
+// The node set for a ray that starts at o (as cast: outside any nested tree): 0 for the set of tight boxes, which only
+// rays starting inside the scene's ball may walk, else the offset of the set of the reference's boxes.  A NaN origin
+// takes the second set.
+__device__ __forceinline__ uint32_t node_set(const DevScene& S, f3 o) {
+    const float x = o.x - S.centre[0], y = o.y - S.centre[1], z = o.z - S.centre[2];
+    return (x * x + y * y + z * z < S.radius2) ? 0u : S.far_set;
+}
 __device__ __forceinline__ void walker_start(Walker& W, const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max) {
     W.o = o; W.d = d;
     box_frame(S, o, d, W.R);
     W.time = time; W.t_min = t_min; W.t_max = t_max;
     W.so = o; W.sd = d;
     W.ret = RT_NODE_NONE; W.ret_end = 0; W.inst_rank = 0; W.inst_xf = 0;
-    W.node = S.surface_root + layout_base(S, d);
+    W.set = node_set(S, o);
+    W.node = S.surface_root + layout_base(S, d) + W.set;
     W.end = W.node + S.surface_size;
     W.leaf = 0;
     W.best.t = INF; W.best.prim = 0xFFFFFFFFu; W.best.sx = 0; W.best.rank = 0;
@@ -688,7 +697,7 @@ __device__ __forceinline__ void walker_leaf(Walker& W, const DevScene& S, Counte
             W.o = no; W.d = nd;
         }
         box_frame(S, W.o, W.d, W.R);
-        W.node = __float_as_uint(G.g[0]) + layout_base(S, W.d);
+        W.node = __float_as_uint(G.g[0]) + layout_base(S, W.d) + W.set;
         W.end = W.node + __float_as_uint(G.g[1]);
         return;
     }
@@ -718,12 +727,12 @@ struct WalkScene {
     const float4* prim_box;
     const float4* prim_inv;
     const float* xforms;
-    uint32_t n_nodes, surface_root, surface_size;
-    float node_scale, inv_node_scale;
+    uint32_t n_nodes, surface_root, surface_size, far_set;
+    float node_scale, inv_node_scale, cx, cy, cz, radius2;
 };
 __device__ __forceinline__ WalkScene walk_scene(const DevScene& S) {
-    return WalkScene{S.nodes, S.prims, S.prim_box, S.prim_inv, S.xforms, S.n_nodes, S.surface_root, S.surface_size,
-                     S.node_scale, S.inv_node_scale};
+    return WalkScene{S.nodes, S.prims, S.prim_box, S.prim_inv, S.xforms, S.n_nodes, S.surface_root, S.surface_size, S.far_set,
+                     S.node_scale, S.inv_node_scale, S.centre[0], S.centre[1], S.centre[2], S.radius2};
 }
 // For a ray whose closest surface hit `best` the reference does not reach (ref_reaches; about one ray in a million):
 // the closest hit behind it that the reference does reach, or none.  The lane walks the surface tree again, on its own,
@@ -734,6 +743,7 @@ __device__ __forceinline__ Closest surface_again(WalkScene A, f3 o, f3 d, float 
     S.nodes = A.nodes; S.prims = A.prims; S.prim_box = A.prim_box; S.prim_inv = A.prim_inv; S.xforms = A.xforms;
     S.n_nodes = A.n_nodes; S.surface_root = A.surface_root; S.surface_size = A.surface_size;
     S.node_scale = A.node_scale; S.inv_node_scale = A.inv_node_scale;
+    S.far_set = A.far_set; S.centre[0] = A.cx; S.centre[1] = A.cy; S.centre[2] = A.cz; S.radius2 = A.radius2;
     const f3 wo = o, wd = d; // the ray as cast
     do {
         const float floor_t = best.t;
@@ -743,7 +753,8 @@ __device__ __forceinline__ Closest surface_again(WalkScene A, f3 o, f3 d, float 
         o = wo; d = wd;
         BoxRay R;
         box_frame(S, o, d, R);
-        uint32_t node = S.surface_root + layout_base(S, d), end = node + S.surface_size;
+        const uint32_t set = node_set(S, wo);
+        uint32_t node = S.surface_root + layout_base(S, d) + set, end = node + S.surface_size;
         uint32_t ret = RT_NODE_NONE, ret_end = 0u, inst_rank = 0u, inst_xf = 0u;
         for (;;) {
             if (node == end) {
@@ -774,7 +785,7 @@ __device__ __forceinline__ Closest surface_again(WalkScene A, f3 o, f3 d, float 
                     o = no; d = nd;
                 }
                 box_frame(S, o, d, R);
-                node = __float_as_uint(G.g[0]) + layout_base(S, d);
+                node = __float_as_uint(G.g[0]) + layout_base(S, d) + set;
                 end = node + __float_as_uint(G.g[1]);
             } else {
                 surface_leaf<true>((const float*)(S.prim_inv + 3u * prim), prim, hd, G, o, d, time, t_min, t_max, inst_rank, inst_xf,
@@ -1215,6 +1226,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
     f3 so = o, sd = d; // outer ray while inside a nested tree
     uint32_t ret = RT_NODE_NONE, ret_end = 0, inst_rank = 0, inst_xf = 0;
     uint32_t node = 0, end = 0; // next node; the walk of the current tree is over at node == end
+    uint32_t set = 0;           // node_set() of the ray (only kept where nested trees are entered)
     uint32_t q0 = 0, q1 = 0, q2 = 0, nq = 0; // leaf queue: q0 newest; entry nq - 1 is the oldest
     Closest best = {INF, 0xFFFFFFFFu, 0u, 0u};
     for (;;) {
@@ -1283,7 +1295,8 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                                 box_frame(S, o, d, R);
                                 time = p0.w;
                                 t_max = INF;
-                                node = S.surface_root + layout_base(S, d);
+                                set = node_set(S, o);
+                                node = S.surface_root + layout_base(S, d) + set;
                                 end = node + S.surface_size;
                                 nq = 0u;
                                 ret = RT_NODE_NONE;
@@ -1331,7 +1344,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                         o = no; d = nd;
                     }
                     box_frame(S, o, d, R);
-                    node = __float_as_uint(G.g[0]) + layout_base(S, d);
+                    node = __float_as_uint(G.g[0]) + layout_base(S, d) + set;
                     end = node + __float_as_uint(G.g[1]);
                 } else {
                     surface_leaf<false>(Tinv, prim, hd, G, o, d, time, t_min, t_max, inst_rank, inst_xf, best, 0.0f, 0u);

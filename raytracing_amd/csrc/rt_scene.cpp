@@ -25,9 +25,10 @@ struct Builder {
     std::string err;
     int status = RT_OK;
 
-    std::vector<uint4> sub_nodes[8];          // nested trees (one copy per octant layout), relative indices
-    std::vector<int64_t> group_root;          // per group: relative root index in sub_nodes, -1 = not emitted
+    std::vector<int64_t> group_root;          // per group: root of its tree relative to the first nested tree, -1 = not collected
     std::vector<uint32_t> group_size;         // per group: nodes in its tree
+    uint32_t n_group_trees = 0;               // nested trees collected so far (tree ids 2, 3, ...)
+    uint32_t group_nodes = 0;                 // ... and their nodes
     std::vector<uint32_t> instance_prims;     // prims whose g0 holds a relative sub-tree root
     std::map<std::vector<uint32_t>, uint32_t> xform_index; // identical matrices share one device record
     std::vector<int> top_pos;                 // object index -> position in `top`
@@ -235,66 +236,17 @@ struct Builder {
         if (++visited > (size_t)4 * (size_t)(T.n_nodes + 1) + 1024) return fail(RT_EINVAL, "BVH links form a cycle");
         return true;
     }
-    static void add_item(std::vector<AccelItem>& items, const float* box, uint32_t prim, uint32_t flags) {
-        AccelItem it;
-        std::memcpy(it.b, box, sizeof(it.b));
+    // ref: the box the reference walks for the primitive; world_lo / world_hi: for an object taken out of a nested tree,
+    // the world-frame bounds of its leaf box in that tree
+    void add_item(uint32_t tree, const float* ref, uint32_t prim, uint32_t flags, const double* world_lo = nullptr,
+                  const double* world_hi = nullptr) {
+        HostItem it;
+        it.tree = tree;
         it.leaf = (prim + 1u) | flags;
-        items.push_back(it);
-    }
-
-    // Bounds of primitive `prim` for the device tree: never larger than the box the reference walks for it (`leaf_box`,
-    // so nothing is found that the reference culls), but tight around spheres and rectangles where the reference's box
-    // is loose (the box of a rotated Transform is the box of eight corners).  The padding covers the rounding of the primitive tests, which accept points slightly outside the exact
-    // shape (src/sphere.jl:46-63 loses about |o - c|^2 / r^2 ulps of the discriminant to cancellation).
-    void tight_box(uint32_t prim, const float* leaf_box, float* out) {
-        std::memcpy(out, leaf_box, 6 * sizeof(float));
-        const uint4 h = H.prims[3 * (size_t)prim], a = H.prims[3 * (size_t)prim + 1];
-        const uint32_t kind = h.x & 15u, field = h.x >> 8;
-        if (h.x & DP_MEDIUM_FLAG) return;
-        const float g[5] = {bitsf(h.w), bitsf(a.x), bitsf(a.y), bitsf(a.z), bitsf(a.w)};
-        double M[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}; // forward matrix, column-major 3x4
-        if (field) for (int k = 0; k < 12; ++k) M[k] = (double)H.xforms[24 * (size_t)(field - 1) + k];
-        auto point = [&M](double x, double y, double z, double* w) {
-            for (int i = 0; i < 3; ++i) w[i] = M[i] * x + M[3 + i] * y + M[6 + i] * z + M[9 + i];
-        };
-        double lo[3], hi[3];
-        if (kind == DP_SPHERE) {
-            double c[3];
-            point(g[0], g[1], g[2], c);
-            double r = std::fabs((double)g[3]);
-            for (int i = 0; i < 3; ++i) {
-                double e = r * std::sqrt(M[i] * M[i] + M[3 + i] * M[3 + i] + M[6 + i] * M[6 + i]);
-                e = e * 1.02 + 4e-6 * std::fabs(c[i]);
-                lo[i] = c[i] - e; hi[i] = c[i] + e;
-            }
-        } else if (kind == DP_XY_RECT || kind == DP_XZ_RECT || kind == DP_YZ_RECT) {
-            const int ka = kind == DP_XY_RECT ? 2 : (kind == DP_XZ_RECT ? 1 : 0); // constant axis
-            const int aa = kind == DP_YZ_RECT ? 1 : 0, ba = kind == DP_XY_RECT ? 1 : 2;
-            for (int i = 0; i < 3; ++i) { lo[i] = INFINITY; hi[i] = -INFINITY; }
-            for (int corner = 0; corner < 8; ++corner) {
-                double p[3], w[3];
-                p[aa] = (corner & 1) ? g[1] : g[0];
-                p[ba] = (corner & 2) ? g[3] : g[2];
-                p[ka] = (double)g[4] + ((corner & 4) ? 0.0001 : -0.0001); // the padding of src/aarect.jl:37-47
-                point(p[0], p[1], p[2], w);
-                for (int i = 0; i < 3; ++i) { lo[i] = std::min(lo[i], w[i]); hi[i] = std::max(hi[i], w[i]); }
-            }
-            double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
-            for (int i = 0; i < 3; ++i) {
-                double e = 1e-4 * ext + 4e-6 * std::max(std::fabs(lo[i]), std::fabs(hi[i]));
-                lo[i] -= e; hi[i] += e;
-            }
-        } else {
-            return;
-        }
-        float box[6];
-        for (int i = 0; i < 3; ++i) {
-            if (!std::isfinite(lo[i]) || !std::isfinite(hi[i])) return;
-            box[i] = std::max(std::nextafter((float)lo[i], -INFINITY), leaf_box[i]);
-            box[3 + i] = std::min(std::nextafter((float)hi[i], INFINITY), leaf_box[3 + i]);
-            if (!(box[i] <= box[3 + i])) return; // NaN or empty: keep the reference's box
-        }
-        std::memcpy(out, box, sizeof(box));
+        std::memcpy(it.ref, ref, sizeof(it.ref));
+        it.inlined = world_lo != nullptr;
+        for (int i = 0; i < 3; ++i) { it.wlo[i] = world_lo ? world_lo[i] : 0.0; it.whi[i] = world_hi ? world_hi[i] : 0.0; }
+        H.items.push_back(it);
     }
 
     // A nested tree taken apart: its objects become primitives of the enclosing tree, each carrying the Transform of the
@@ -311,7 +263,7 @@ struct Builder {
     }
 
     // generic tree (src/BVH.jl)
-    bool collect_generic(const rtBvh& T, int id, int depth, std::vector<AccelItem>& items, uint32_t rank_base,
+    bool collect_generic(const rtBvh& T, int id, int depth, uint32_t tree, uint32_t rank_base,
                          const std::vector<uint32_t>* rank_offset, bool nested, int nested_top, const Inlined* inl = nullptr) {
         if (!check_node(T, id, depth)) return false;
         if (T.node_leaf[id - 1]) {
@@ -342,7 +294,7 @@ struct Builder {
                         Inlined ctx{xf, leaf_box};
                         size_t saved = visited;
                         visited = 0;
-                        bool ok = collect_generic(G, 1, 0, items, rank, &offsets, true, top, &ctx);
+                        bool ok = collect_generic(G, 1, 0, tree, rank, &offsets, true, top, &ctx);
                         visited = saved;
                         return ok;
                     }
@@ -353,8 +305,8 @@ struct Builder {
             uint32_t head = H.prims[3 * (size_t)prim].x;
             bool instance = (head & 15u) == DP_INSTANCE;
             set_ref_boxes(prim, nested ? (inl ? inl->clip_box : nullptr) : leaf_box, nested ? leaf_box : nullptr);
-            float world_box[6];
-            if (inl) { // the object-frame box of the leaf, as a world-frame box inside the box of the whole nested tree
+            const uint32_t flags = instance ? RT_LEAF_INSTANCE : ((head >> 8) ? RT_LEAF_XFORM : 0u);
+            if (inl) { // the object-frame box of the leaf in the world frame; the reference's box is that of the whole nested tree
                 double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
                 double M[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
                 if (inl->xf) for (int k = 0; k < 12; ++k) M[k] = (double)H.xforms[24 * (size_t)(inl->xf - 1) + k];
@@ -366,41 +318,24 @@ struct Builder {
                         lo[i] = std::min(lo[i], w); hi[i] = std::max(hi[i], w);
                     }
                 }
-                bool ok = true;
-                for (int i = 0; i < 3; ++i) {
-                    double e = 1e-5 * (hi[i] - lo[i]) + 4e-6 * std::max(std::fabs(lo[i]), std::fabs(hi[i]));
-                    world_box[i] = std::max(std::nextafter((float)(lo[i] - e), -INFINITY), inl->clip_box[i]);
-                    world_box[3 + i] = std::min(std::nextafter((float)(hi[i] + e), INFINITY), inl->clip_box[3 + i]);
-                    if (!(world_box[i] <= world_box[3 + i])) ok = false;
-                }
-                if (!ok) std::memcpy(world_box, inl->clip_box, sizeof(world_box)); // NaN / infinite: the box of the whole tree
-                leaf_box = world_box;
+                add_item(tree, inl->clip_box, prim, flags, lo, hi);
+            } else {
+                add_item(tree, leaf_box, prim, flags);
             }
-            float box[6];
-            tight_box(prim, leaf_box, box);
-            add_item(items, box, prim, instance ? RT_LEAF_INSTANCE : ((head >> 8) ? RT_LEAF_XFORM : 0u));
             return true;
         }
-        return collect_generic(T, T.node_left[id - 1], depth + 1, items, rank_base, rank_offset, nested, nested_top, inl) &&
-               collect_generic(T, T.node_right[id - 1], depth + 1, items, rank_base, rank_offset, nested, nested_top, inl);
+        return collect_generic(T, T.node_left[id - 1], depth + 1, tree, rank_base, rank_offset, nested, nested_top, inl) &&
+               collect_generic(T, T.node_right[id - 1], depth + 1, tree, rank_base, rank_offset, nested, nested_top, inl);
     }
 
-    // Builds the device tree over `items` and appends its eight layouts to dst[0..7]; every layout gets the same
-    // number of nodes, so one layout-relative root index serves all of them.
-    void emit_tree(std::vector<AccelItem>& items, std::vector<uint4>* dst) {
-        if (items.empty()) return;
-        AccelTree tree;
-        accel_build(items, tree);
-        for (int o = 0; o < 8; ++o) accel_emit(tree, o, H.node_scale, dst[o]);
-    }
-
+    // A nested tree kept as an instance: its objects are collected into a tree of their own (a binary tree over n leaves
+    // has 2n - 1 nodes, so root and size are known before any box is).
     bool emit_group(int gi, int top, int64_t& root) {
         if (group_root[(size_t)gi] >= 0) { root = group_root[(size_t)gi]; return true; }
         const rtBvh& T = D.groups[gi];
         if (T.kind != 0) return fail(RT_EUNSUPPORTED, "nested tree of meshes is not supported");
         if (T.n_objects <= 0 || T.n_nodes <= 0 || !T.objects || !T.node_bounds || !T.node_left || !T.node_right || !T.node_leaf)
             return fail(RT_EINVAL, "empty or incomplete nested tree");
-        std::vector<AccelItem> items;
         size_t saved = visited;
         visited = 0;
         std::vector<uint32_t> offsets;
@@ -409,14 +344,16 @@ struct Builder {
             offsets.push_back(acc);
             acc += flat_count(T.objects[k]);
         }
-        bool ok = collect_generic(T, 1, 0, items, 0u, &offsets, true, top);
+        const uint32_t tree = 2u + n_group_trees++;
+        const size_t first_item = H.items.size();
+        bool ok = collect_generic(T, 1, 0, tree, 0u, &offsets, true, top);
         visited = saved;
         if (!ok) return false;
-        size_t start = sub_nodes[0].size();
-        emit_tree(items, sub_nodes);
-        group_root[(size_t)gi] = (int64_t)start;
-        group_size[(size_t)gi] = (uint32_t)(sub_nodes[0].size() - start);
-        root = (int64_t)start;
+        const uint32_t n_items = (uint32_t)(H.items.size() - first_item);
+        group_root[(size_t)gi] = (int64_t)group_nodes;
+        group_size[(size_t)gi] = n_items ? 2u * n_items - 1u : 0u;
+        group_nodes += group_size[(size_t)gi];
+        root = group_root[(size_t)gi];
         return true;
     }
 
@@ -444,8 +381,7 @@ struct Builder {
     }
 
     // tree over meshes (src/mesh.jl:250-283): every triangle becomes a primitive with its own bounding box
-    bool collect_tris(const rtBvh& T, const rtMesh& M, int top, int id, int depth, uint32_t rank_base,
-                      std::vector<AccelItem>& items) {
+    bool collect_tris(const rtBvh& T, const rtMesh& M, int top, int id, int depth, uint32_t rank_base, uint32_t tree) {
         if (!check_node(T, id, depth)) return false;
         if (T.node_leaf[id - 1] == 1) {
             int l = T.node_left[id - 1], r = T.node_right[id - 1];
@@ -469,33 +405,18 @@ struct Builder {
                 uint32_t type = ((uint32_t)D.materials[material].type << 5) & DP_TYPE_MASK;
                 uint32_t prim = push_prim(DP_TRIANGLE | type | (attr << 8), (uint32_t)material, rank_base + (uint32_t)(c - 1), g, top,
                                           M.tri_ids ? M.tri_ids[c - 1] : c - 1);
-                // The triangle's own bounds, padded: the barycentric test of src/triangle.jl:73-91 accepts points a few
-                // rounding errors outside the exact triangle, and the box must not cull those.
-                float box[6], ext = 0.0f, mag = 0.0f;
-                for (int ax = 0; ax < 3; ++ax) {
-                    float lo = std::min(g[ax], std::min(g[3 + ax], g[6 + ax])), hi = std::max(g[ax], std::max(g[3 + ax], g[6 + ax]));
-                    box[ax] = lo; box[3 + ax] = hi;
-                    ext = std::max(ext, hi - lo);
-                    mag = std::max(mag, std::max(std::fabs(lo), std::fabs(hi)));
-                }
-                float pad = 1e-4f * ext + 4e-6f * mag;
-                // never larger than the box the reference walks for this triangle (the leaf's box)
                 const float* lb = T.node_bounds + 6 * (size_t)(id - 1);
                 set_ref_boxes(prim, lb, nullptr);
-                for (int ax = 0; ax < 3; ++ax) {
-                    box[ax] = std::max(box[ax] - pad, std::min(lb[ax], box[ax]));
-                    box[3 + ax] = std::min(box[3 + ax] + pad, std::max(lb[3 + ax], box[3 + ax]));
-                }
-                add_item(items, box, prim, 0u);
+                add_item(tree, lb, prim, 0u);
             }
             return true;
         }
         if (T.node_leaf[id - 1] != 0) return fail(RT_EINVAL, "reached an unused BVH node slot");
-        return collect_tris(T, M, top, T.node_left[id - 1], depth + 1, rank_base, items) &&
-               collect_tris(T, M, top, T.node_right[id - 1], depth + 1, rank_base, items);
+        return collect_tris(T, M, top, T.node_left[id - 1], depth + 1, rank_base, tree) &&
+               collect_tris(T, M, top, T.node_right[id - 1], depth + 1, rank_base, tree);
     }
     bool collect_mesh_level(const rtBvh& T, int id, int depth, uint32_t rank_base, const std::vector<uint32_t>& rank_offset,
-                            std::vector<AccelItem>& items) {
+                            uint32_t tree) {
         if (!check_node(T, id, depth)) return false;
         if (T.node_leaf[id - 1] > 1) return fail(RT_EINVAL, "reached an unused BVH node slot");
         if (T.node_leaf[id - 1]) {
@@ -506,10 +427,10 @@ struct Builder {
             int mi = D.objects[oi].aux;
             if (mi < 0 || mi >= D.n_meshes) return fail(RT_EINVAL, "mesh index out of range");
             return collect_tris(T, D.meshes[mi], top_pos[(size_t)oi], T.node_left[id - 1], depth + 1,
-                                rank_base + rank_offset[(size_t)(pos - 1)], items);
+                                rank_base + rank_offset[(size_t)(pos - 1)], tree);
         }
-        return collect_mesh_level(T, T.node_left[id - 1], depth + 1, rank_base, rank_offset, items) &&
-               collect_mesh_level(T, T.node_right[id - 1], depth + 1, rank_base, rank_offset, items);
+        return collect_mesh_level(T, T.node_left[id - 1], depth + 1, rank_base, rank_offset, tree) &&
+               collect_mesh_level(T, T.node_right[id - 1], depth + 1, rank_base, rank_offset, tree);
     }
 
     bool run() {
@@ -539,51 +460,204 @@ struct Builder {
         }
         std::vector<uint32_t> base((size_t)D.n_buckets, 0);
         for (int b = D.n_buckets - 2; b >= 0; --b) base[(size_t)b] = base[(size_t)b + 1] + totals[(size_t)b + 1];
-        // region 0: one tree over every surface; region 1: one tree over the constant media (walked after the surfaces)
+        // tree 0: every surface; tree 1: the constant media (walked after the surfaces); trees 2..: nested trees kept as
+        // instances.  Collected here as leaves with the reference's boxes; rt_build_nodes makes the device trees.
         choose_node_scale();
-        std::vector<uint4> main_nodes[8];
-        for (int region = 0; region < 2; ++region) {
-            std::vector<AccelItem> items;
+        uint32_t n_main[2] = {0, 0};
+        for (uint32_t region = 0; region < 2; ++region) {
+            const size_t before = H.items.size();
             for (int b = 0; b < D.n_buckets; ++b) {
                 const rtBvh& T = D.buckets[b];
                 int first = T.objects[0];
                 bool is_medium = valid_obj(first) && D.objects[first].kind == RT_CONSTANT_MEDIUM;
                 if (is_medium != (region == 1)) continue;
                 visited = 0;
-                bool ok = T.kind == 1 ? collect_mesh_level(T, 1, 0, base[(size_t)b], offsets[(size_t)b], items)
-                                      : collect_generic(T, 1, 0, items, base[(size_t)b], &offsets[(size_t)b], false, -1);
+                bool ok = T.kind == 1 ? collect_mesh_level(T, 1, 0, base[(size_t)b], offsets[(size_t)b], region)
+                                      : collect_generic(T, 1, 0, region, base[(size_t)b], &offsets[(size_t)b], false, -1);
                 if (!ok) return false;
             }
-            uint32_t region_start = (uint32_t)main_nodes[0].size();
-            emit_tree(items, main_nodes);
-            uint32_t region_size = (uint32_t)main_nodes[0].size() - region_start;
-            (region == 0 ? H.surface_root : H.medium_root) = region_start;
-            (region == 0 ? H.surface_size : H.medium_size) = region_size;
+            for (size_t k = before; k < H.items.size(); ++k) n_main[region] += H.items[k].tree == region ? 1u : 0u;
         }
-        // the nested trees go behind the two regions; the eight layouts follow one another
-        const uint64_t main_count = main_nodes[0].size(), sub_count = sub_nodes[0].size();
-        const uint64_t per_layout = main_count + sub_count;
-        if (8 * per_layout >= (uint64_t)RT_NODE_LEAF - 1u) return fail(RT_EUNSUPPORTED, "too many BVH nodes");
+        // layout of one octant: surfaces, media, then the nested trees in the order they were collected
+        H.surface_root = 0;
+        H.surface_size = n_main[0] ? 2u * n_main[0] - 1u : 0u;
+        H.medium_root = H.surface_size;
+        H.medium_size = n_main[1] ? 2u * n_main[1] - 1u : 0u;
+        const uint64_t main_count = (uint64_t)H.surface_size + H.medium_size;
+        const uint64_t per_layout = main_count + group_nodes;
+        if (16 * per_layout >= (uint64_t)RT_NODE_LEAF - 1u) return fail(RT_EUNSUPPORTED, "too many BVH nodes");
         if (H.prims.size() / 3 >= (size_t)RT_LEAF_PRIM_MASK) return fail(RT_EUNSUPPORTED, "too many primitives");
         H.nodes_per_layout = (uint32_t)per_layout;
-        H.nested = sub_count != 0;
-        H.nodes.reserve((size_t)(8 * per_layout));
-        for (int o = 0; o < 8; ++o) {
-            // skip links (interior nodes) become absolute; leaf words stay
-            const uint32_t shift = (uint32_t)(o * per_layout);
-            for (uint4& n : main_nodes[o])
-                if (!(n.w & RT_NODE_LEAF)) n.w += shift;
-            for (uint4& n : sub_nodes[o])
-                if (!(n.w & RT_NODE_LEAF)) n.w += (uint32_t)main_count + shift;
-            H.nodes.insert(H.nodes.end(), main_nodes[o].begin(), main_nodes[o].end());
-            H.nodes.insert(H.nodes.end(), sub_nodes[o].begin(), sub_nodes[o].end());
+        H.nested = group_nodes != 0;
+        H.tree_first.assign(2u + n_group_trees, 0u);
+        H.tree_first[1] = H.medium_root;
+        {
+            std::vector<uint32_t> count(2u + n_group_trees, 0u);
+            for (const HostItem& it : H.items) count[it.tree]++;
+            uint32_t at = (uint32_t)main_count;
+            for (uint32_t t = 2; t < 2u + n_group_trees; ++t) { H.tree_first[t] = at; at += count[t] ? 2u * count[t] - 1u : 0u; }
         }
         for (uint32_t p : instance_prims) H.prims[3 * (size_t)p].w += (uint32_t)main_count; // g0 holds the root as raw bits
+        H.scene_reach = 0.0;
+        for (const HostItem& it : H.items)
+            for (int k = 0; k < 6; ++k)
+                if (std::isfinite(it.ref[k])) H.scene_reach = std::max(H.scene_reach, (double)std::fabs(it.ref[k]));
+        rt_build_nodes(&H, 2.0 * H.scene_reach);
         return true;
     }
 };
 
+// Bounds of primitive `prim` for the tight node set: never larger than `loose` (the box the reference walks for it,
+// so nothing is found that the reference culls), but tight around spheres and rectangles where the reference's box is
+// loose (the box of a rotated Transform is the box of eight corners).  The primitive tests accept points slightly outside
+// the exact shape, the further the ray has come the more: the sphere test (src/sphere.jl:46-63) loses about
+// 15 ulp * |o - c|^2 of its discriminant to cancellation, the rectangle test (src/aarect.jl:49-95) about 3 ulp * |o - p|
+// of the in-plane coordinates.  The padding covers that for rays that start within *valid_for of the primitive;
+// returns false (out = loose) if the primitive is not tightened.
+bool tight_box(const HostScene& H, uint32_t prim, const float* loose, float* out, double* valid_for) {
+    std::memcpy(out, loose, 6 * sizeof(float));
+    const uint4 h = H.prims[3 * (size_t)prim], a = H.prims[3 * (size_t)prim + 1];
+    const uint32_t kind = h.x & 15u, field = h.x >> 8;
+    if (h.x & DP_MEDIUM_FLAG) return false;
+    if (kind != DP_SPHERE && kind != DP_XY_RECT && kind != DP_XZ_RECT && kind != DP_YZ_RECT) return false;
+    const float g[5] = {bitsf(h.w), bitsf(a.x), bitsf(a.y), bitsf(a.z), bitsf(a.w)};
+    double M[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}; // forward matrix, column-major 3x4
+    if (field) for (int k = 0; k < 12; ++k) M[k] = (double)H.xforms[24 * (size_t)(field - 1) + k];
+    auto point = [&M](double x, double y, double z, double* w) {
+        for (int i = 0; i < 3; ++i) w[i] = M[i] * x + M[3 + i] * y + M[6 + i] * z + M[9 + i];
+    };
+    double lo[3], hi[3];
+    if (kind == DP_SPHERE) {
+        double c[3];
+        point(g[0], g[1], g[2], c);
+        const double r = std::fabs((double)g[3]);
+        double shrink = INFINITY; // smallest stretch of the matrix along an axis (1 for rotations)
+        for (int i = 0; i < 3; ++i) {
+            const double n = std::sqrt(M[i] * M[i] + M[3 + i] * M[3 + i] + M[6 + i] * M[6 + i]);
+            shrink = std::min(shrink, n);
+            const double e = r * n * 1.02 + 4e-6 * std::fabs(c[i]);
+            lo[i] = c[i] - e; hi[i] = c[i] + e;
+        }
+        // 1.02^2 - 1 = 0.0404 of r^2 against 15 * 2^-24 * |o - c|^2: |o - c| < 212 r
+        *valid_for = 200.0 * r * shrink;
+    } else {
+        const int ka = kind == DP_XY_RECT ? 2 : (kind == DP_XZ_RECT ? 1 : 0); // constant axis
+        const int aa = kind == DP_YZ_RECT ? 1 : 0, ba = kind == DP_XY_RECT ? 1 : 2;
+        for (int i = 0; i < 3; ++i) { lo[i] = INFINITY; hi[i] = -INFINITY; }
+        for (int corner = 0; corner < 8; ++corner) {
+            double p[3], w[3];
+            p[aa] = (corner & 1) ? g[1] : g[0];
+            p[ba] = (corner & 2) ? g[3] : g[2];
+            p[ka] = (double)g[4] + ((corner & 4) ? 0.0001 : -0.0001); // the padding of src/aarect.jl:37-47
+            point(p[0], p[1], p[2], w);
+            for (int i = 0; i < 3; ++i) { lo[i] = std::min(lo[i], w[i]); hi[i] = std::max(hi[i], w[i]); }
+        }
+        const double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+        for (int i = 0; i < 3; ++i) {
+            const double e = 1e-4 * ext + 4e-6 * std::max(std::fabs(lo[i]), std::fabs(hi[i]));
+            lo[i] -= e; hi[i] += e;
+        }
+        *valid_for = 250.0 * ext; // 1e-4 ext against 3 * 2^-24 * |o - p| (and as much again for the transform of the ray)
+    }
+    float box[6];
+    bool tighter = false;
+    for (int i = 0; i < 3; ++i) {
+        if (!std::isfinite(lo[i]) || !std::isfinite(hi[i])) return false;
+        box[i] = std::max(std::nextafter((float)lo[i], -INFINITY), loose[i]);
+        box[3 + i] = std::min(std::nextafter((float)hi[i], INFINITY), loose[3 + i]);
+        if (!(box[i] <= box[3 + i])) return false; // NaN or empty: keep the reference's box
+        tighter = tighter || box[i] != loose[i] || box[3 + i] != loose[3 + i];
+    }
+    if (!tighter) return false;
+    std::memcpy(out, box, sizeof(box));
+    return true;
+}
+
 } // namespace
+
+// Node sets.  Every leaf gets two boxes:
+//   loose: the box the reference walks for it.  For an object taken out of a nested tree that is the box of its leaf in
+//          that tree, carried into the world frame and padded by 2e-6 * reach -- the reference tests that box with the
+//          ray taken into the tree's frame, which moves the ray by up to ~1e-6 of its origin's coordinates and of the
+//          distance it has come -- and cut to the box of the whole nested tree (which the reference tests with the ray as cast).
+//   tight: tight_box() of that, valid for rays that start close enough to the primitive.
+// Set 0 is built from the tight boxes and serves the rays that start inside a ball in which all of them are valid; set 1,
+// from the loose boxes, serves the others (rays scattered far out in a scene-wide medium, a camera far away).  Without a
+// tightened primitive (or without a ball) there is one set.  A leaf holds one primitive, so both sets have the same
+// trees at the same places.
+void rt_build_nodes(HostScene* out, double reach) {
+    HostScene& H = *out;
+    H.reach = reach;
+    const size_t n = H.items.size();
+    std::vector<AccelItem> loose(n), tight(n);
+    double csum[3] = {0, 0, 0};
+    std::vector<double> valid(n, INFINITY);
+    size_t n_tight = 0;
+    for (size_t k = 0; k < n; ++k) {
+        const HostItem& it = H.items[k];
+        loose[k].leaf = tight[k].leaf = it.leaf;
+        std::memcpy(loose[k].b, it.ref, sizeof(it.ref));
+        if (it.inlined) {
+            const double pad = 2e-6 * reach;
+            float box[6];
+            bool ok = true;
+            for (int i = 0; i < 3; ++i) {
+                box[i] = std::max(std::nextafter((float)(it.wlo[i] - pad), -INFINITY), it.ref[i]);
+                box[3 + i] = std::min(std::nextafter((float)(it.whi[i] + pad), INFINITY), it.ref[3 + i]);
+                if (!(box[i] <= box[3 + i])) ok = false;
+            }
+            if (ok) std::memcpy(loose[k].b, box, sizeof(box)); // NaN / infinite: the box of the whole nested tree
+        }
+        const uint32_t prim = (it.leaf & RT_LEAF_PRIM_MASK) - 1u;
+        if (tight_box(H, prim, loose[k].b, tight[k].b, &valid[k])) {
+            n_tight++;
+            for (int i = 0; i < 3; ++i) csum[i] += 0.5 * ((double)tight[k].b[i] + (double)tight[k].b[3 + i]);
+        } else {
+            valid[k] = INFINITY;
+        }
+    }
+    double radius = INFINITY;
+    H.centre[0] = H.centre[1] = H.centre[2] = 0.0f;
+    if (n_tight) {
+        for (int i = 0; i < 3; ++i) H.centre[i] = (float)(csum[i] / (double)n_tight);
+        for (size_t k = 0; k < n; ++k) {
+            if (valid[k] == INFINITY) continue;
+            double d2 = 0;
+            for (int i = 0; i < 3; ++i) {
+                const double c = 0.5 * ((double)tight[k].b[i] + (double)tight[k].b[3 + i]) - (double)H.centre[i];
+                d2 += c * c;
+            }
+            radius = std::min(radius, valid[k] - std::sqrt(d2));
+        }
+    }
+    const bool two_sets = n_tight != 0 && radius > 0.0 && std::isfinite(radius);
+    if (n_tight != 0 && !two_sets) tight = loose; // no ball in which every tight box is valid: one set of loose boxes
+    H.n_sets = two_sets ? 2u : 1u;
+    H.radius = two_sets ? (float)(radius * 0.999) : INFINITY;
+    const uint32_t n_trees = (uint32_t)H.tree_first.size();
+    const uint32_t per_layout = H.nodes_per_layout;
+    H.nodes.clear();
+    H.nodes.reserve((size_t)H.n_sets * 8u * per_layout);
+    for (uint32_t set = 0; set < H.n_sets; ++set) {
+        const std::vector<AccelItem>& boxes = set == 0 ? tight : loose;
+        std::vector<uint4> layout[8];
+        for (uint32_t t = 0; t < n_trees; ++t) {
+            std::vector<AccelItem> items;
+            for (size_t k = 0; k < n; ++k) if (H.items[k].tree == t) items.push_back(boxes[k]);
+            if (items.empty()) continue;
+            AccelTree tree;
+            accel_build(items, tree);
+            for (int o = 0; o < 8; ++o) accel_emit(tree, o, H.node_scale, layout[o]);
+        }
+        for (uint32_t o = 0; o < 8; ++o) {
+            // skip links (interior nodes) become absolute; leaf words stay
+            const uint32_t shift = (set * 8u + o) * per_layout;
+            for (uint4& nd : layout[o])
+                if (!(nd.w & RT_NODE_LEAF)) nd.w += shift;
+            H.nodes.insert(H.nodes.end(), layout[o].begin(), layout[o].end());
+        }
+    }
+}
 
 int rt_flatten_scene(const rtSceneDesc* desc, HostScene* out) {
     if (!desc || !out) return rt_fail(RT_EINVAL, "rt_flatten_scene: null argument");

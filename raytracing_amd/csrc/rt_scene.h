@@ -9,9 +9,29 @@
 #include "../../include/rt_amd.h"
 #include "rt_device.h"
 
+// One leaf of a device tree, as the scene description gives it: what rt_build_nodes turns into boxes.
+struct HostItem {
+    uint32_t tree;       // 0: surfaces, 1: constant media, 2 + k: k-th nested tree kept as an instance
+    uint32_t leaf;       // leaf word: (primitive index + 1) | RT_LEAF_* flags
+    float ref[6];        // the box the reference walks for it: its leaf's box -- for an object taken out of a nested tree
+                         // the box of that tree's leaf in the enclosing tree (world frame)
+    bool inlined;        // object of a nested tree (Transform{BVHTree}) taken into the enclosing tree
+    double wlo[3], whi[3]; // inlined: world-frame bounds of the object's leaf box in the nested tree, unpadded
+};
+
 struct HostScene {
-    std::vector<uint4> nodes;  // 1 per node; eight layouts of nodes_per_layout nodes each, one per ray octant
+    // Nodes: n_sets * 8 layouts of nodes_per_layout nodes each (one layout per ray octant).  Set 0 holds tight boxes,
+    // valid for rays that start inside the ball (centre, radius); set 1 (present if n_sets == 2) the reference's own
+    // boxes, valid for every ray that starts within `reach` of the origin.
+    std::vector<uint4> nodes;
     uint32_t nodes_per_layout = 0;
+    uint32_t n_sets = 1;
+    float centre[3] = {0.0f, 0.0f, 0.0f};
+    float radius = __builtin_inff();
+    double reach = 0.0;        // largest |coordinate| of a ray origin the node boxes were built for
+    double scene_reach = 0.0;  // largest finite |coordinate| of the scene's own boxes
+    std::vector<HostItem> items;
+    std::vector<uint32_t> tree_first; // first node (layout-relative) of every tree in `items`' numbering
     float node_scale = 1.0f; // power of two the node boxes are multiplied by
     bool nested = false; // nested trees (Transform{BVHTree}) present
     bool textured = false; // a texture other than SolidColor present
@@ -30,7 +50,10 @@ struct HostScene {
     uint32_t surface_root = 0, surface_size = 0, medium_root = 0, medium_size = 0; // layout-relative roots, node counts
 };
 
-// validates the description and fills `out`; returns an rtStatus and sets rt_last_error()
+// validates the description and fills `out` (nodes built for rays that start inside the scene); returns an rtStatus
+// and sets rt_last_error()
 int rt_flatten_scene(const rtSceneDesc* desc, HostScene* out);
+// (re)builds out->nodes and the ball of set 0 for ray origins with |coordinate| <= reach
+void rt_build_nodes(HostScene* out, double reach);
 
 #endif

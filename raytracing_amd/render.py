@@ -32,15 +32,17 @@ def _pattern(pattern):
 
 def scene_layout(world):
     """The acceleration structure the library builds for `world` (rt_scene_layout; computed on the host, no GPU needed).
-    Returns (info, nodes, prim_top): nodes is a (8, nodes_per_layout, 4) uint32 array (one copy per ray octant; words
-    0-2 hold the box as six IEEE halves, word 3 the link), prim_top[k] the position of primitive k in `world`."""
+    Returns (info, nodes, prim_top): nodes is a (8 * n_sets, nodes_per_layout, 4) uint32 array (per node set one copy per
+    ray octant; words 0-2 hold the box as six IEEE halves, word 3 the link; set 0: tight boxes for rays that start inside
+    the ball (info.centre, info.radius), set 1 if present: the reference's boxes), prim_top[k] the position of primitive
+    k in `world`."""
     world = list(world)
     bvh = build_bvh_scene(SceneManager(world))
     desc, keep = flatten_scene(world, bvh)
     info = ffi.rtLayout()
     L = ffi.lib()
     ffi.check(L.rt_scene_layout(C.byref(desc), C.byref(info), None, 0, None, 0))
-    nodes = np.zeros((8, info.nodes_per_layout, 4), dtype=np.uint32)
+    nodes = np.zeros((8 * info.n_sets, info.nodes_per_layout, 4), dtype=np.uint32)
     prim_top = np.zeros(info.n_prims, dtype=np.int32)
     ffi.check(L.rt_scene_layout(C.byref(desc), C.byref(info), nodes.ctypes.data_as(C.POINTER(C.c_uint32)), nodes.size // 4,
                                 ffi.iptr(prim_top), prim_top.size))

@@ -1,5 +1,6 @@
-"""The device acceleration structure (own SAH trees, eight ray-octant layouts, 16-byte half-precision nodes) checked on
-the host through rt_scene_layout: structure, coverage of the primitives, box enclosure, and that the stackless walk
+"""The device acceleration structure (own SAH trees, eight ray-octant layouts per node set, 16-byte half-precision
+nodes; one set of tight boxes for rays that start inside the scene's ball, one of the reference's boxes for the others)
+checked on the host through rt_scene_layout: structure, coverage of the primitives, box enclosure, and that the stackless walk
 visits every primitive whose reference bounding box (src/*.jl bounding_box) the ray passes -- the walk may only cull
 what the reference's exact slab test (src/bounding_box.jl:20-67) culls too.  No GPU needed."""
 import numpy as np
@@ -45,14 +46,19 @@ def layouts():
 def test_structure_and_coverage(name, layouts):
     world, kw, info, nodes, prim_top = layouts(name)
     N = info.nodes_per_layout
-    assert nodes.shape == (8, N, 4) and N > 0 and info.n_prims == len(prim_top)
+    assert info.n_sets in (1, 2) and nodes.shape == (8 * info.n_sets, N, 4) and N > 0 and info.n_prims == len(prim_top)
+    assert (info.n_sets == 2) == bool(np.isfinite(info.radius)) and info.radius > 0
     scale = info.node_scale
     assert scale > 0 and np.log2(scale) == np.round(np.log2(scale))          # a power of two
     ref = None
-    for o in range(8):
-        link = nodes[o, :, 3].astype(np.int64)
-        box = boxes_of(nodes[o], o)
-        base = o * N
+    leaf_boxes = {}
+    for layout in range(8 * info.n_sets):
+        o = layout % 8
+        if o == 0:
+            ref = None
+        link = nodes[layout, :, 3].astype(np.int64)
+        box = boxes_of(nodes[layout], o)
+        base = layout * N
         # every primitive is the leaf of exactly one node of the layout
         leaves = link[(link & LEAF) != 0]
         prims = (leaves & PRIM_MASK) - 1
@@ -80,13 +86,20 @@ def test_structure_and_coverage(name, layouts):
                     assert np.all(box[c, :3] >= box[i, :3]) and np.all(box[c, 3:] <= box[i, 3:])
                 stack += [c1, c2]
             assert seen == size and subtree_end(rel, root) == root + size
-        # the eight layouts hold the same nodes (boxes, leaf words), only in different orders
+        if o == 0:
+            is_leaf = (link & LEAF) != 0
+            leaf_boxes[layout // 8] = box[is_leaf][np.argsort((link[is_leaf] & PRIM_MASK) - 1)]
+        # the eight layouts of a set hold the same nodes (boxes, leaf words), only in different orders
         key = np.concatenate([box.view(np.uint32), np.where((link & LEAF) != 0, link, 0).astype(np.uint32)[:, None]], axis=1)
         key = key[np.lexsort(key.T[::-1])]
         if ref is None:
             ref = key
         else:
             assert np.array_equal(ref, key)
+    # the tight boxes of set 0 lie inside the boxes of set 1 (up to the outward rounding of both)
+    if info.n_sets == 2:
+        a, b = leaf_boxes[0], leaf_boxes[1]
+        assert np.all(a[:, :3] >= b[:, :3]) and np.all(a[:, 3:] <= b[:, 3:]) and np.any(a != b)
     # layouts of opposite octants visit the children of the root in opposite order
     if info.surface_size > 1:
         r = info.surface_root
@@ -111,13 +124,18 @@ def walk(nodes, info, octant, root, size, o, d, t_min=0.001):
         oi = ((o * scale).astype(F) * inv).astype(F)
         slack = (np.abs(oi) * F(2.0 ** -22)).astype(F)
         cn, cf = (-oi - slack).astype(F), (-oi + slack).astype(F)
-    link = nodes[octant, :, 3]
-    planes = nodes[octant, :, :3].copy().view(np.float16).astype(np.float64)     # x near, x far, y near, y far, z near, z far
-    node = octant * N + root
+    # node set: the tight one for rays that start inside the ball, else the last one (node_set() of rt_kernels.hip)
+    with np.errstate(invalid="ignore", over="ignore"):
+        rel = (o - np.asarray(info.centre, F)).astype(F)
+        inside = F(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]) < F(info.radius) * F(info.radius)
+    layout = (0 if inside else info.n_sets - 1) * 8 + octant
+    link = nodes[layout, :, 3]
+    planes = nodes[layout, :, :3].copy().view(np.float16).astype(np.float64)     # x near, x far, y near, y far, z near, z far
+    node = layout * N + root
     end = node + size
     out = []
     while node != end:
-        i = node - octant * N
+        i = node - layout * N
         with np.errstate(invalid="ignore", over="ignore"):
             # plane * inv + c, fused (one rounding): the product of a half and a float is exact in float64
             t0 = (planes[i, 0::2] * inv.astype(np.float64) + cn.astype(np.float64)).astype(F)
@@ -154,13 +172,15 @@ def slab_exact(bmin, bmax, o, d, t_min=0.001):
     return True
 
 
-def must_visit(obj, o, d, t_min=0.001):
+def must_visit(obj, o, d, tight, t_min=0.001):
     """True if the reference can report a hit of `obj` for the ray: the ray passes the reference's bounding box of the
-    object (exact slab test) and, for the shapes whose device boxes are tighter than the reference's, also meets the
-    shape itself (in float64, with the ray taken into the object's frame like src/transform.jl:104-105)."""
+    object (exact slab test) and, for a ray that walks the set of tight boxes, also meets the shape itself (in float64,
+    with the ray taken into the object's frame like src/transform.jl:104-105)."""
     b = H.bounding_box(obj)
     if not slab_exact(b.min, b.max, o, d, t_min):
         return False
+    if not tight:
+        return True
     shape, oo, dd = obj, o.astype(np.float64), d.astype(np.float64)
     if isinstance(shape, H.Transform):
         T = np.asarray(shape.inv_xform, np.float64).reshape(4, 3).T       # column-major 3x4
@@ -190,7 +210,7 @@ def test_walk_never_culls_what_the_reference_visits(name, layouts):
     centre = 0.5 * (lo[finite].min(axis=0) + hi[finite].max(axis=0))
     extent = (hi[finite].max(axis=0) - lo[finite].min(axis=0)).max()
     n_rays = 64
-    n_must = 0
+    n_must = n_far = 0
     # rays that run inside a face of an object's reference box (origin on the plane, direction parallel to it): the
     # reference's slab test ignores the 0 * Inf = NaN of that axis and goes on to the primitive
     special = []
@@ -211,6 +231,9 @@ def test_walk_never_culls_what_the_reference_visits(name, layouts):
         elif k % 2 == 0:   # from the camera towards the scene
             o = np.asarray(cam.origin, np.float32)
             target = centre + rng.uniform(-0.5, 0.5, 3) * extent
+        elif k % 16 == 5:  # from far outside (beyond the ball of the tight set, if there is one) towards the scene
+            o = (centre + rng.choice([-1.0, 1.0], 3) * rng.uniform(4.0, 9.0, 3) * extent).astype(np.float32)
+            target = centre + rng.uniform(-0.3, 0.3, 3) * extent
         else:            # between two points inside the scene bounds (secondary rays), incl. axis-parallel ones
             o = (centre + rng.uniform(-0.5, 0.5, 3) * extent).astype(np.float32)
             target = centre + rng.uniform(-0.5, 0.5, 3) * extent
@@ -225,11 +248,17 @@ def test_walk_never_culls_what_the_reference_visits(name, layouts):
         for root, size in ((info.surface_root, info.surface_size), (info.medium_root, info.medium_size)):
             if size:
                 visited |= {prim_top[(w & PRIM_MASK) - 1] for w in walk(nodes, info, octant, root, size, o, d)}
+        rel = o.astype(np.float64) - np.asarray(info.centre, np.float64)
+        tight = info.n_sets == 2 and rel @ rel < 0.99 * float(info.radius) ** 2
+        if info.n_sets == 2 and not tight and rel @ rel < 1.01 * float(info.radius) ** 2:
+            continue  # too close to the ball's surface to say which set the kernel's float32 test picks
+        n_far += 0 if tight else 1
         for idx in range(len(world)):
-            if must_visit(world[idx], o, d):
+            if must_visit(world[idx], o, d, tight):
                 n_must += 1
                 assert idx in visited, (name, k, idx, type(world[idx]).__name__)
     assert n_must > n_rays  # the rays do meet the scene
+    assert info.n_sets == 1 or 0 < n_far < n_rays  # ... and both node sets were walked
 
 
 def test_nested_tree_inlined_or_kept(monkeypatch):
@@ -241,3 +270,6 @@ def test_nested_tree_inlined_or_kept(monkeypatch):
     assert info2.nested == 1 and info2.n_prims == info.n_prims + 1      # + the instance primitive
     assert info2.surface_size < info.surface_size
     assert sorted(set(prim_top)) == sorted(set(prim_top2))
+    # rotated spheres: tight boxes in the first set, valid inside a ball around them; the nested tree itself is walked in
+    # its own frame, where a sphere's box is the reference's: nothing to tighten, one set
+    assert info.n_sets == 2 and 0 < info.radius < 1e5 and info2.n_sets == 1

@@ -236,6 +236,44 @@ def test_boxes_the_reference_culls():
         dev.close()
 
 
+@pytest.mark.parametrize("inline", ["1", "0"])
+def test_boxes_the_reference_culls_around_a_nested_tree(inline, monkeypatch):
+    """The same from far away for a Transform{BVHTree}: the reference tests the box of the whole tree with the ray as
+    cast and the boxes inside with the ray in the tree's frame (src/transform.jl:104-116 around src/BVH.jl:22-53).  A tree
+    of thin rectangles and small spheres, seen from 40000 away, both ways the device can hold such a tree; few slots, so
+    that slots on hold are met by several launches."""
+    import math
+    from raytracing_amd import build_bvh
+    from raytracing_amd.hittables import (Camera, Emissive, Lambertian, Material, RotY, Sphere, Transform, Vec3, affine,
+                                          xy_rect, xz_rect)
+    rng = np.random.default_rng(5)
+    grey, light = Material(Lambertian, Vec3(0.6, 0.6, 0.6)), Material(Emissive, Vec3(2, 2, 2))
+    members = []
+    for k in range(40):
+        c = rng.uniform(-200, 200, 3)
+        members.append(Sphere(Vec3(*c), float(rng.uniform(5, 25)), grey) if k % 2 else
+                       xy_rect(c[0] - 30, c[0] + 30, c[1] - 30, c[1] + 30, float(c[2]), light if k % 4 == 0 else grey))
+    world = [Transform(build_bvh(members), affine(RotY(math.radians(20)), [10, 20, 30])),
+             xz_rect(-400, 400, -400, 400, -250, grey), Sphere(Vec3(0, 0, 900), 500, light)]
+    origin = Vec3(0, 100, -40000)
+    cam = Camera(origin, origin - Vec3(0, 0, 0), Vec3(0, 1, 0), 1.2, 1.0, 0.0, 10.0, 0.0, 1.0)
+    monkeypatch.setenv("RT_AMD_INLINE_GROUPS", inline)
+    monkeypatch.setenv("RT_AMD_SLOTS", "16384")
+    ref, dev = O.OracleScene(world), rt.DeviceScene(world)
+    try:
+        rays = O.primary_rays(cam, 80, 80, 80, 80)
+        a, b = ref.trace_rays(rays), dev.trace_rays(rays)
+        np.testing.assert_array_equal(a["prim_id"], b["prim_id"])
+        np.testing.assert_array_equal(a["sub_id"], b["sub_id"])
+        np.testing.assert_array_equal(bits(a["t"]), bits(b["t"]))
+        assert (a["prim_id"] == 0).sum() > 100
+        pat = rt.Halton_sequence32(8)
+        img, st = dev.render(cam, pat, Vec3(0.1, 0.1, 0.1), 80, 80)
+        np.testing.assert_array_equal(bits(img), bits(ref.render(cam, pat, Vec3(0.1, 0.1, 0.1), 80, 80)))
+    finally:
+        dev.close()
+
+
 def test_nested_tree_kept_as_instance(scenes, monkeypatch):
     """By default the objects of a Transform{BVHTree} are taken into the enclosing device tree; with
     RT_AMD_INLINE_GROUPS=0 the tree stays a nested instance (entered and left by the extend kernel).  Same image."""
