@@ -249,7 +249,8 @@ void rt_obj_free(rtObjMesh* mesh);
  * little capacity only fills `info` (and returns RT_OK), so a first call sizes the buffers. */
 typedef struct rtLayout {
     uint32_t nodes_per_layout, n_prims;
-    uint32_t surface_root, surface_size, medium_root, medium_size; /* layout-relative roots, node counts */
+    uint32_t surface_root, surface_size; /* layout-relative root of the tree of surfaces, its node count */
+    uint32_t medium_root, medium_size;   /* medium_size = 0: the constant media are kept as a list, not in a tree */
     uint32_t nested;    /* 1 if nested trees follow the two main trees */
     float node_scale;   /* power of two the stored boxes were multiplied by */
     uint32_t n_sets;    /* node sets (8 layouts each): 1, or 2 = {tight boxes, the reference's boxes} */

@@ -201,6 +201,7 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     if (st == RT_OK) st = upload(s, H.image_data, &s->dev.image_data);
     if (st == RT_OK) st = upload(s, H.perlin_vec, &s->dev.perlin_vec);
     if (st == RT_OK) st = upload(s, H.perlin_perm, &s->dev.perlin_perm);
+    if (st == RT_OK) st = upload(s, H.media, &s->dev.media);
     if (st == RT_OK) st = upload(s, H.prim_top, &s->dev.prim_top);
     if (st == RT_OK) st = upload(s, H.prim_sub, &s->dev.prim_sub);
     if (st == RT_OK) {
@@ -221,8 +222,7 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     s->dev.n_prims = (uint32_t)(H.prims.size() / 3);
     s->dev.surface_root = H.surface_root;
     s->dev.surface_size = H.surface_size;
-    s->dev.medium_root = H.medium_root;
-    s->dev.medium_size = H.medium_size;
+    s->dev.n_media = (uint32_t)H.media.size();
     s->dev.nested = H.nested ? 1u : 0u;
     s->dev.textured = H.textured ? 1u : 0u;
     *out = s;

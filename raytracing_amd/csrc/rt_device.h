@@ -66,6 +66,7 @@ struct DevScene {
     const uint8_t* image_data;
     const float* perlin_vec;     // 768 floats per perlin
     const int32_t* perlin_perm;  // 768 ints per perlin (x, y, z)
+    const uint32_t* media;       // the constant media (primitive indices) in descending rank
     const int32_t* prim_top;     // per primitive: position in the world vector (reported prim_id)
     const int32_t* prim_sub;     // per primitive: reported sub id base (triangle id / nested object index)
     uint32_t n_nodes, n_prims; // n_nodes: nodes per octant layout
@@ -78,7 +79,7 @@ struct DevScene {
     uint32_t surface_root, surface_size; // root of the surface tree (layout-relative) and its node count (0: no surfaces)
     uint32_t nested;       // 1 if the scene holds nested trees (Transform{BVHTree})
     uint32_t textured;     // 1 if any texture is not a SolidColor
-    uint32_t medium_root, medium_size;   // the same for the tree of constant media
+    uint32_t n_media;      // entries in `media`
 };
 
 #endif

@@ -618,29 +618,32 @@ __device__ __forceinline__ void node_step(const DevScene& S, const BoxRay& R, fl
     leaf = (hit && is_leaf) ? (link & ~RT_NODE_LEAF) : 0u;
 }
 
-// The constant media of the scene for a ray whose closest surface is already in `best` (best.t = INF: none).
-// Every lane walks the (small) medium tree on its own; callers run this with all lanes of a wave active.
+// The constant media of the scene for a ray whose closest surface is already in `best` (best.t = INF: none; best.rank
+// must be the surface's rank).  The reference meets the objects of a scene in a fixed order -- type group after type
+// group, inside a group in the order of its tree walk -- and tests each with the closest distance found so far as t_max
+// (src/scene_manager.jl:40-53, src/BVH.jl:22-53); for a medium that bound cuts the path through the boundary
+// (src/constant_medium.jl:36-44), so it matters what was found before it.  Ranks are that order (higher = met earlier):
+// the media are taken in descending rank, each with the bound the reference would have had -- the closest medium so
+// far, and the surface only if it ranks higher.  Every lane of a wave meets the same medium in the same step.
+// (The media are few -- a scene-wide fog, a smoke box or two -- so they are a list, not a tree.)
 __device__ __forceinline__ void media_closest(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max,
                                               const RngKey& key, Closest& best) {
-    if (S.medium_size == 0u) return;
-    uint32_t node = S.medium_root + layout_base(S, d);
-    const uint32_t end = node + S.medium_size;
-    BoxRay R;
-    box_frame(S, o, d, R);
-    if (best.t != INF) t_max = best.t;
-    while (node != end) {
-        uint32_t leaf;
-        node_step(S, R, t_min, t_max, node, leaf);
-        if (leaf) {
-            uint32_t prim = (leaf & RT_LEAF_PRIM_MASK) - 1u;
-            uint4 head;
-            Geom G;
-            load_prim(S, prim, head, G);
-            if (!ref_reaches<true>(S, prim, 0u, o, d, t_min, t_max)) continue;
-            float t = medium_t(S, head.x, G.g, o, d, time, t_min, t_max, key);
-            consider(best, t_max, t, prim, ((head.x >> 8) << 3) | ((head.x & DP_TYPE_MASK) << 24), head.z);
-        }
+    Closest medium = {INF, 0xFFFFFFFFu, 0u, 0u};
+    float t_medium = INF;
+#pragma unroll 1
+    for (uint32_t k = 0; k < S.n_media; ++k) {
+        const uint32_t prim = S.media[k];
+        uint4 head;
+        Geom G;
+        load_prim(S, prim, head, G);
+        float lim = fminf(t_medium, t_max);
+        if (best.rank > head.z) lim = fminf(lim, best.t);
+        if (!ref_reaches<true>(S, prim, 0u, o, d, t_min, lim)) continue;
+        float t = medium_t(S, head.x, G.g, o, d, time, t_min, lim, key);
+        consider(medium, t_medium, t, prim, ((head.x >> 8) << 3) | ((head.x & DP_TYPE_MASK) << 24), head.z);
     }
+    float unused = INF;
+    consider(best, unused, medium.t, medium.prim, medium.sx, medium.rank);
 }
 
 // back out of a nested tree (its walk is over): restore the outer ray
@@ -1147,7 +1150,7 @@ __device__ __forceinline__ void camera_ray(const RtCameraDev& cam, const float* 
 #define QP(pool, plane, slot) (pool).q[(size_t)(plane) * (pool).n_slots + (slot)]
 #define HIT_MISS 6u
 #define HIT_WAIT 7u                  // shade kernel: the slot waits for rt_redo_kernel, nothing to shade yet
-#define RANK_SETTLED 0xFFFFFFFFu     // rank word of a hit record that rt_redo_kernel has settled
+#define RANK_SETTLED 0x80000000u     // bit of the rank word of a hit record: rt_redo_kernel has settled the hit
 #define EXTEND_CHUNK 256u
 
 // random-number key of the path at pixel r (row-major) and column kk of the batch; returns the pattern column
@@ -1400,7 +1403,7 @@ __global__ void __launch_bounds__(256) rt_redo_kernel(DevScene S, PathPool pool,
         Closest best;
         best.t = h.x; best.prim = __float_as_uint(h.y); best.sx = __float_as_uint(h.z); best.rank = __float_as_uint(h.w);
         best = surface_again(walk_scene(S), mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), p0.w, 0.001f, INF, best);
-        QP(pool, 3, slot) = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(RANK_SETTLED));
+        QP(pool, 3, slot) = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(best.rank | RANK_SETTLED));
     }
     __syncthreads();
     if (threadIdx.x == 0u && n != 0u) {
@@ -1443,9 +1446,10 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
             // stand the slot is put on hold: rt_redo_kernel finds the hit that does, and the slot is shaded a few
             // launches later.
             Closest best;
-            best.t = q4.x; best.prim = __float_as_uint(q4.y); best.sx = __float_as_uint(q4.z); best.rank = 0u;
+            best.t = q4.x; best.prim = __float_as_uint(q4.y); best.sx = __float_as_uint(q4.z);
+            best.rank = __float_as_uint(q4.w) & ~RANK_SETTLED;
             const bool held = (__float_as_uint(q1.w) & DEPTH_HOLD) != 0u;
-            if (held && __float_as_uint(q4.w) != RANK_SETTLED) {
+            if (held && !(__float_as_uint(q4.w) & RANK_SETTLED)) {
                 q4.w = __uint_as_float(HIT_WAIT); // still waiting for rt_redo_kernel
             } else if (!held && best.t != INF && !ref_reaches<false>(S, best.prim, (best.sx >> 3) & 0x3FFFFFFu, o, d, 0.001f, INF)) {
                 // plane 3 keeps {t, prim, sx, rank} of the hit that does not stand: where the redo starts from
@@ -1453,7 +1457,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
                 pool.redo[atomicAdd(sync + RT_REDO_COUNT, 1u)] = base + t;
                 q4.w = __uint_as_float(HIT_WAIT);
             } else {
-                if (S.medium_size != 0u) {
+                if (S.n_media != 0u) {
                     RngKey key;
                     path_key(P, (__float_as_uint(q1.w) >> DEPTH_COLUMN_SHIFT) & DEPTH_COLUMN_MASK, __float_as_uint(q2.w), key);
                     key.bounce = (uint32_t)(P.max_depth - depth0);

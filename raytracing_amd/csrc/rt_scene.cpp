@@ -460,8 +460,9 @@ struct Builder {
         }
         std::vector<uint32_t> base((size_t)D.n_buckets, 0);
         for (int b = D.n_buckets - 2; b >= 0; --b) base[(size_t)b] = base[(size_t)b + 1] + totals[(size_t)b + 1];
-        // tree 0: every surface; tree 1: the constant media (walked after the surfaces); trees 2..: nested trees kept as
-        // instances.  Collected here as leaves with the reference's boxes; rt_build_nodes makes the device trees.
+        // tree 0: every surface; "tree" 1: the constant media, which the kernels take as a list after the surfaces (they are
+        // few) -- no nodes are built for them; trees 2..: nested trees kept as instances.  Collected here as leaves with the
+        // reference's boxes; rt_build_nodes makes the device trees.
         choose_node_scale();
         uint32_t n_main[2] = {0, 0};
         for (uint32_t region = 0; region < 2; ++region) {
@@ -482,7 +483,7 @@ struct Builder {
         H.surface_root = 0;
         H.surface_size = n_main[0] ? 2u * n_main[0] - 1u : 0u;
         H.medium_root = H.surface_size;
-        H.medium_size = n_main[1] ? 2u * n_main[1] - 1u : 0u;
+        H.medium_size = 0u;
         const uint64_t main_count = (uint64_t)H.surface_size + H.medium_size;
         const uint64_t per_layout = main_count + group_nodes;
         if (16 * per_layout >= (uint64_t)RT_NODE_LEAF - 1u) return fail(RT_EUNSUPPORTED, "too many BVH nodes");
@@ -496,8 +497,14 @@ struct Builder {
             for (const HostItem& it : H.items) count[it.tree]++;
             uint32_t at = (uint32_t)main_count;
             for (uint32_t t = 2; t < 2u + n_group_trees; ++t) { H.tree_first[t] = at; at += count[t] ? 2u * count[t] - 1u : 0u; }
+            if (at != per_layout) return fail(RT_EINVAL, "internal: node count of the nested trees does not add up");
         }
         for (uint32_t p : instance_prims) H.prims[3 * (size_t)p].w += (uint32_t)main_count; // g0 holds the root as raw bits
+        for (const HostItem& it : H.items)
+            if (it.tree == 1u) H.media.push_back((it.leaf & RT_LEAF_PRIM_MASK) - 1u);
+        std::sort(H.media.begin(), H.media.end(), [this](uint32_t a, uint32_t b) {
+            return H.prims[3 * (size_t)a].z > H.prims[3 * (size_t)b].z; // rank: higher = met earlier by the reference
+        });
         H.scene_reach = 0.0;
         for (const HostItem& it : H.items)
             for (int k = 0; k < 6; ++k)
@@ -642,6 +649,7 @@ void rt_build_nodes(HostScene* out, double reach) {
         const std::vector<AccelItem>& boxes = set == 0 ? tight : loose;
         std::vector<uint4> layout[8];
         for (uint32_t t = 0; t < n_trees; ++t) {
+            if (t == 1u) continue; // the constant media are a list, not a tree
             std::vector<AccelItem> items;
             for (size_t k = 0; k < n; ++k) if (H.items[k].tree == t) items.push_back(boxes[k]);
             if (items.empty()) continue;

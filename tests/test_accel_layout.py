@@ -59,10 +59,12 @@ def test_structure_and_coverage(name, layouts):
         link = nodes[layout, :, 3].astype(np.int64)
         box = boxes_of(nodes[layout], o)
         base = layout * N
-        # every primitive is the leaf of exactly one node of the layout
+        # every surface primitive is the leaf of exactly one node of the layout (the constant media are kept as a list:
+        # the kernels try every medium for every ray)
         leaves = link[(link & LEAF) != 0]
         prims = (leaves & PRIM_MASK) - 1
-        assert np.array_equal(np.sort(prims), np.arange(info.n_prims))
+        surfaces = np.array([k for k in range(info.n_prims) if not isinstance(world[prim_top[k]], H.ConstantMedium)])
+        assert np.array_equal(np.sort(prims), surfaces) and info.medium_size == 0
         # skip links stay inside the layout and point forward
         inter = np.nonzero((link & LEAF) == 0)[0]
         assert np.all(link[inter] > inter + base) and np.all(link[inter] <= base + N)
@@ -254,6 +256,8 @@ def test_walk_never_culls_what_the_reference_visits(name, layouts):
             continue  # too close to the ball's surface to say which set the kernel's float32 test picks
         n_far += 0 if tight else 1
         for idx in range(len(world)):
+            if isinstance(world[idx], H.ConstantMedium):
+                continue
             if must_visit(world[idx], o, d, tight):
                 n_must += 1
                 assert idx in visited, (name, k, idx, type(world[idx]).__name__)
