@@ -1,5 +1,5 @@
-// accel_build.h -- the device-side acceleration structure: one binary BVH per region (surfaces, media, every nested
-// tree), built with the surface-area heuristic over the primitives' bounding boxes and laid out once per ray-direction
+// accel_build.h -- the device-side acceleration structure: one binary BVH over the surfaces and one per nested
+// tree kept as an instance, built with the surface-area heuristic over the primitives' bounding boxes and laid out once per ray-direction
 // octant so that the stackless walk of rt_kernels.hip meets the near child of every node first.
 #ifndef ACCEL_BUILD_H
 #define ACCEL_BUILD_H

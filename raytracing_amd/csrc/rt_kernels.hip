@@ -440,7 +440,7 @@ __device__ __forceinline__ bool ref_reaches(const DevScene& S, uint32_t prim, ui
 // a group, the leaf its right-child-first stack order reaches first -- encoded here as `rank`.
 //
 // Surfaces and constant media are walked one after the other: first the tree of surfaces (the Walker below, or the
-// state machine of rt_extend_kernel), then the tree of media (media_closest), so that the (expensive, stochastic)
+// state machine of rt_extend_kernel), then the list of media (media_closest), so that the (expensive, stochastic)
 // medium test runs with the closest surface already known.
 //
 // The surface walk is a per-lane state machine with two blocks, walker_step (fetch one node, box test) and
