@@ -105,6 +105,38 @@ class DeviceScene:
         ffi.check(ffi.lib().rt_finalize_rgb8(self.handle, C.c_void_p(d_accum), n_total, width, height,
                                              C.c_void_p(d_rgb8), C.c_void_p(stream or 0)))
 
+    def render_progressive(self, camera, pattern, background, width, height, passes=8, state=None, max_depth=50,
+                           seed=DEFAULT_SEED):
+        """Progressive refinement with resume.  The pattern columns are dealt to `passes` interleaved shards (shard c =
+        columns c, c + passes, ...: the sample sharding of the multi-GPU path, in time instead of across GPUs); after
+        every shard the generator yields (state, img): img is the picture of the columns traced so far (same layout as
+        render()), state a dict of host arrays {"accum", "next", "passes", "n", "done"} that np.savez can store and a
+        later call takes back through `state=` to go on where it stopped.  After the last shard the image equals
+        render()'s up to the order of the float32 sums."""
+        import torch
+        pat, n = _pattern(pattern)
+        passes = max(1, min(int(passes), n))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        stream = torch.cuda.current_stream().cuda_stream
+        total = torch.zeros(3 * width * height, dtype=torch.float32, device=dev)
+        first, done = 0, 0
+        if state is not None:
+            if int(state["passes"]) != passes or int(state["n"]) != n or np.asarray(state["accum"]).size != total.numel():
+                raise ValueError("render_progressive: the state belongs to a different pattern, pass count or image size")
+            total.copy_(torch.from_numpy(np.ascontiguousarray(state["accum"], dtype=F)))
+            first, done = int(state["next"]), int(state["done"])
+        part = torch.empty_like(total)
+        out = torch.empty_like(total)
+        for c in range(first, passes):
+            self.accumulate(camera, pattern, background, width, height, part.data_ptr(), sample_first=c,
+                            sample_stride=passes, max_depth=max_depth, seed=seed, stream=stream)
+            total += part
+            done += len(range(c, n, passes))
+            self.finalize(total.data_ptr(), done, width, height, out.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            img = out.cpu().numpy().reshape(width, height, 3).transpose(1, 0, 2).copy()
+            yield dict(accum=total.cpu().numpy(), next=c + 1, passes=passes, n=n, done=done), img
+
     def counters(self):
         st = ffi.rtStats()
         ffi.check(ffi.lib().rt_get_counters(self.handle, C.byref(st)))

@@ -295,6 +295,36 @@ def test_nested_tree_kept_as_instance(scenes, monkeypatch):
     np.testing.assert_array_equal(bits(a["t"]), bits(b["t"]))
 
 
+def test_progressive_rendering_and_resume(scenes, tmp_path):
+    """render_progressive: interleaved shards of the pattern, an image after each; stopped after two shards, stored with
+    np.savez, resumed from the file: the final image is the one-shot image up to float32 summation order, and the same
+    whether or not the run was interrupted."""
+    world, kw, dev, ref = scenes("cornell_smoke_box")
+    cam, bg = kw["camera"], kw["background"]
+    pat = rt.Halton_sequence32(20)
+    W, H = 48, 40
+    full, _ = dev.render(cam, pat, bg, W, H)
+    steps = list(dev.render_progressive(cam, pat, bg, W, H, passes=5))
+    assert [s["done"] for s, _ in steps] == [4, 8, 12, 16, 20]
+    np.testing.assert_allclose(steps[-1][1], full, rtol=2e-6, atol=1e-7)
+    # the first shard alone is the picture of pattern columns 0, 5, 10, 15
+    sub, _ = dev.render(cam, pat[:, 0::5], bg, W, H)
+    assert np.abs(steps[0][1] - sub).max() > 0            # other sample indices -> other random streams ...
+    lin = lambda im: float((im.astype(np.float64) ** 2).mean())           # the gamma is a square root
+    assert abs(lin(steps[0][1]) - lin(full)) < 0.25 * lin(full)            # ... but the same picture
+    gen = dev.render_progressive(cam, pat, bg, W, H, passes=5)
+    next(gen)
+    state, _ = next(gen)
+    gen.close()
+    np.savez(tmp_path / "state.npz", **state)
+    stored = dict(np.load(tmp_path / "state.npz"))
+    rest = list(dev.render_progressive(cam, pat, bg, W, H, passes=5, state=stored))
+    assert [s["done"] for s, _ in rest] == [12, 16, 20]
+    np.testing.assert_array_equal(bits(rest[-1][1]), bits(steps[-1][1]))
+    with pytest.raises(ValueError):
+        next(dev.render_progressive(cam, pat, bg, W, H, passes=4, state=stored))
+
+
 def test_device_output_stage_matches_host_quantisation(scenes):
     """rt_finalize_rgb8 (clamp01 + N0f8 on the device) == rt_finalize followed by the host quantisation"""
     import torch
