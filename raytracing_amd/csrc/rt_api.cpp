@@ -147,10 +147,10 @@ int fill_params(const float background[3], int width, int height, int max_depth,
     P->seed32 = fold_seed(seed);
     P->background[0] = background[0]; P->background[1] = background[1]; P->background[2] = background[2];
     P->image_floats = (size_t)3 * (size_t)width * (size_t)height;
-    P->leaf_threshold = (uint32_t)env_int("RT_AMD_LEAF_THRESHOLD", 40);
+    P->leaf_threshold = (uint32_t)env_int("RT_AMD_LEAF_THRESHOLD", 32);
     P->blocked_threshold = (uint32_t)env_int("RT_AMD_BLOCKED_THRESHOLD", 12);
-    P->fetch_threshold = (uint32_t)env_int("RT_AMD_FETCH_THRESHOLD", 16);
-    P->step_dropout = (uint32_t)env_int("RT_AMD_STEP_DROPOUT", 8);
+    P->fetch_threshold = (uint32_t)env_int("RT_AMD_FETCH_THRESHOLD", 28);
+    P->step_dropout = (uint32_t)env_int("RT_AMD_STEP_DROPOUT", 12);
     P->regroup = std::getenv("RT_AMD_NO_REGROUP") ? 0u : 1u;
     return RT_OK;
 }
@@ -286,12 +286,13 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
     P.sample_first = sample_first;
     P.sample_stride = sample_stride;
     const uint32_t n_shard_samples = (uint32_t)((n - sample_first + sample_stride - 1) / sample_stride);
-    // Slots in flight: enough rays per launch to fill the machine many times over (default 4 M).
+    // Slots in flight: enough rays per launch to fill the machine many times over (default 3.5 Mi: measured optimum for
+    // cu_cover2 between more launches per frame and a larger working set).
     PathPool pool;
     uint64_t total_paths = (uint64_t)P.n_pixels * n_shard_samples;
     // A multiple of 16 Ki, so that the paths the slots start with cover whole rounds of the path dispensers.
     const uint32_t slot_quantum = RT_DISP_UNIT * RT_DISP_MAX;
-    pool.n_slots = (uint32_t)env_int("RT_AMD_SLOTS", 4 * 1024 * 1024) / slot_quantum * slot_quantum;
+    pool.n_slots = (uint32_t)env_int("RT_AMD_SLOTS", 3584 * 1024) / slot_quantum * slot_quantum;
     if (pool.n_slots < slot_quantum) pool.n_slots = slot_quantum;
     if ((uint64_t)pool.n_slots > total_paths) pool.n_slots = (uint32_t)((total_paths + 1023ull) / 1024ull * 1024ull);
     // The radiance of every path is kept until its pixel is summed, so the frame is cut into batches of pattern
