@@ -1516,7 +1516,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
         done = shade<TEXTURED>(S, mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), q0.w, best, ps,
                      mk3(P.background[0], P.background[1], P.background[2]), key, result, no, nd);
         if (done) {
-            radiance[(size_t)kk * P.n_pixels + r] = make_float4(result.x, result.y, result.z, 0.0f);
+            {   // written once, read once at the end of the batch: kept out of the caches the path pool lives in
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                v4f rv = {result.x, result.y, result.z, 0.0f};
+                __builtin_nontemporal_store(rv, reinterpret_cast<v4f*>(&radiance[(size_t)kk * P.n_pixels + r]));
+            }
         } else {
             cont = true;
             // the colour is +0 until a path ends in every scene the reference can describe; it only takes memory
