@@ -45,6 +45,8 @@ struct rtScene {
     float4* d_radiance = nullptr; size_t radiance_cap = 0; // one entry per path of the batch in flight
     float4* d_pool = nullptr;   size_t pool_cap = 0;   // path state planes of the wavefront renderer
     uint32_t* d_redo = nullptr; size_t redo_cap = 0;   // slots on hold (PathPool::redo)
+    float4* d_pool2 = nullptr;  size_t pool2_cap = 0;  // second pool, for the compaction at the end of a frame
+    uint32_t* d_counts = nullptr; size_t counts_cap = 0; // ... and its counts per 256 slots
     uint32_t* d_sync = nullptr;                        // [0] slot dispenser head, [1..] active-slot counts per bounce
     uint32_t* h_sync = nullptr;                        // pinned mirror of the activity flag
     uint32_t h_init[RT_SYNC_WORDS];                    // staging of the initial sync array
@@ -258,6 +260,8 @@ int rt_scene_destroy(rtScene* s) {
     if (s->d_radiance) (void)hipFree(s->d_radiance);
     if (s->d_pool) (void)hipFree(s->d_pool);
     if (s->d_redo) (void)hipFree(s->d_redo);
+    if (s->d_pool2) (void)hipFree(s->d_pool2);
+    if (s->d_counts) (void)hipFree(s->d_counts);
     if (s->d_sync) (void)hipFree(s->d_sync);
     if (s->h_sync) (void)hipHostFree(s->h_sync);
     if (s->events) {
@@ -329,7 +333,12 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
     RtCameraDev cam;
     camera_to_dev(camera, &cam);
     uint32_t extend_blocks = (uint32_t)(s->n_cus > 0 ? s->n_cus : 256) * (uint32_t)env_int("RT_AMD_EXTEND_BLOCKS_PER_CU", 6);
+    const uint32_t frame_slots = pool.n_slots;
     for (uint32_t k0 = 0; k0 < n_shard_samples; k0 += (uint32_t)cols) {
+        pool.n_slots = frame_slots;
+        pool.q = s->d_pool;
+        bool tail = false; // the device reported that no unstarted path is left
+        const uint32_t batch = BOUNCE_BATCH;
         P.k_begin = k0;
         P.k_end = k0 + (uint32_t)cols < n_shard_samples ? k0 + (uint32_t)cols : n_shard_samples;
         P.n_paths = (P.k_end - P.k_begin) * P.n_pixels;
@@ -350,27 +359,43 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
         HIP_TRY(hipGetLastError());
         // Bounce loop: the device reports after every bounce how many slots still hold a ray; the host enqueues
         // bounces in batches and stops after the first batch that ends with none.
-        for (uint64_t bounce = 0;; bounce += BOUNCE_BATCH) {
+        for (uint64_t bounce = 0;; bounce += batch) {
             HIP_TRY(hipMemsetAsync(s->d_sync + 2, 0, BOUNCE_BATCH * sizeof(uint32_t), stream));
             if (bounce != 0) rt_launch_redo(&s->dev, &pool, s->d_sync, stream);
-            for (uint32_t b = 0; b < BOUNCE_BATCH; ++b)
+            // No unstarted path left: the slots run dry over the next (up to max_depth) bounces.  The ones that still
+            // hold a ray are moved together, so that the launches shrink with them.
+            if (tail && pool.n_slots > 4096u && !std::getenv("RT_AMD_NO_COMPACT")) {
+                st = ensure(&s->d_pool2, &s->pool2_cap, (size_t)5 * frame_slots);
+                if (st == RT_OK) st = ensure(&s->d_counts, &s->counts_cap, (size_t)frame_slots / 256 + 2);
+                if (st != RT_OK) return st;
+                float4* to = pool.q == s->d_pool ? s->d_pool2 : s->d_pool;
+                rt_launch_compact(&pool, to, s->d_counts, s->d_sync, stream);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(s->h_sync + 1, s->d_sync + RT_LIVE_SLOTS, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                pool.n_slots = RT_COMPACT_SLOTS(s->h_sync[1], pool.n_slots);
+                pool.q = to;
+            }
+            for (uint32_t b = 0; b < batch; ++b)
                 rt_launch_bounce(&s->dev, &cam, s->d_pattern, &P, &pool, extend_blocks, s->d_radiance, s->d_sync,
                                  s->d_sync + 2u + b, s->d_counters, count, timing ? s->events + 3u * b : nullptr, stream);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(s->h_sync, s->d_sync + 1u + BOUNCE_BATCH, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(s->h_sync, s->d_sync + 1u + batch, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(s->h_sync + 2, s->d_sync + RT_TAIL_FLAG, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             if (timing) {
-                for (uint32_t b = 0; b < BOUNCE_BATCH; ++b) {
+                for (uint32_t b = 0; b < batch; ++b) {
                     float ms_e = 0.0f, ms_s = 0.0f;
                     HIP_TRY(hipEventElapsedTime(&ms_e, s->events[3u * b], s->events[3u * b + 1u]));
                     HIP_TRY(hipEventElapsedTime(&ms_s, s->events[3u * b + 1u], s->events[3u * b + 2u]));
                     s->last_extend_s += (double)ms_e * 1e-3;
                     s->last_shade_s += (double)ms_s * 1e-3;
                 }
-                s->last_extend_launches += BOUNCE_BATCH;
-                s->last_shade_launches += BOUNCE_BATCH;
+                s->last_extend_launches += batch;
+                s->last_shade_launches += batch;
             }
             if (s->h_sync[0] == 0u) break;
+            tail = s->h_sync[2] != 0u;
             if (bounce > ((uint64_t)P.n_paths / pool.n_slots + 2ull) * 64ull + 4096ull)
                 return rt_fail(RT_EHIP, "rt_render_accumulate: bounce loop did not terminate");
         }

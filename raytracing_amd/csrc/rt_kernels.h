@@ -19,6 +19,8 @@ struct RtCameraDev { // same field order as rtCamera (src/camera.jl:3-14)
 #define RT_SLOT_DISP 64u   // slot dispensers of the extend kernel (each hands out one contiguous share of the slots)
 #define RT_SLOT_DISP_BASE (RT_DISP_BASE + RT_DISP_MAX * RT_DISP_STRIDE)
 #define RT_REDO_COUNT (RT_SLOT_DISP_BASE + RT_SLOT_DISP * RT_DISP_STRIDE) // entries in PathPool::redo; + 1: finished workgroups of rt_redo_kernel
+#define RT_TAIL_FLAG (RT_REDO_COUNT + 2u)  // set once a workgroup found no unstarted path left: slots now only run dry
+#define RT_LIVE_SLOTS (RT_REDO_COUNT + 3u) // written by rt_launch_compact: slots that hold a ray
 #define RT_SYNC_WORDS (RT_REDO_COUNT + RT_DISP_STRIDE)
 
 struct PathPool { // per-slot path state, five float4 planes of n_slots entries each (see rt_kernels.hip)
@@ -55,6 +57,12 @@ void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, const float* d_
                       unsigned long long* d_counters, bool count, hipEvent_t* timing, hipStream_t stream);
 // settles the slots that the shade kernel put on hold since the last call; to be enqueued between batches of bounces
 void rt_launch_redo(const DevScene* S, const PathPool* pool, uint32_t* d_sync, hipStream_t stream);
+// The slots of `from` that hold a ray, moved to the front of the pool `to` (same order), which has
+// RT_COMPACT_SLOTS(their number, from->n_slots) slots, the others marked empty; d_sync[RT_LIVE_SLOTS] receives their
+// number.  d_counts: scratch, from->n_slots / 256 + 2 words.
+#define RT_COMPACT_SLOTS(live, n_slots) (((live) + 1023u) / 1024u * 1024u < 1024u ? 1024u : (((live) + 1023u) / 1024u * 1024u > (n_slots) ? (n_slots) : ((live) + 1023u) / 1024u * 1024u))
+// For the end of a frame, when no unstarted path is left and the slots run dry over up to max_depth bounces.
+void rt_launch_compact(const PathPool* from, float4* to, uint32_t* d_counts, uint32_t* d_sync, hipStream_t stream);
 void rt_launch_sum(const RtRenderParams* P, const float4* d_radiance, float* d_accum, int first_batch, hipStream_t stream);
 void rt_launch_finalize(const float* d_accum, float inv_n, size_t image_floats, float* d_out, hipStream_t stream);
 void rt_launch_finalize_rgb8(const float* d_accum, float inv_n, int width, int height, uint8_t* d_out, hipStream_t stream);

@@ -1554,6 +1554,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
                     if (v < P.disp_limit) { block_base = v; block_disp = c; }
                 }
             }
+            if (block_base == 0xFFFFFFFFu) sync[RT_TAIL_FLAG] = 1u; // every writer stores the same value
         }
     }
     __syncthreads();
@@ -1575,6 +1576,64 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
     if ((t & 63u) == 0u && m) atomicAdd(&block_alive, (uint32_t)__popcll(m));
     __syncthreads();
     if (t == 0u && block_alive) *active = 1u; // every writer stores the same value: no atomic needed
+}
+
+// ---- compaction of the path pool at the end of a frame: count the slots that hold a ray per 256, prefix sums, move
+__global__ void __launch_bounds__(256) rt_compact_count_kernel(PathPool pool, uint32_t* __restrict__ counts) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    const bool holds = s < pool.n_slots && (__float_as_uint(QP(pool, 1, s).w) & DEPTH_MASK) != 0u;
+    __shared__ uint32_t n;
+    if (threadIdx.x == 0u) n = 0u;
+    __syncthreads();
+    const unsigned long long m = __ballot(holds);
+    if ((threadIdx.x & 63u) == 0u && m) atomicAdd(&n, (uint32_t)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0u) counts[blockIdx.x] = n;
+}
+// one workgroup: counts[0 .. n_blocks) -> exclusive prefix sums in place, the total to counts[n_blocks] and the sync word;
+// the slots of `to` from the total up to the next multiple of 1024 are marked empty
+__global__ void __launch_bounds__(1024) rt_compact_scan_kernel(uint32_t* __restrict__ counts, uint32_t n_blocks, float4* __restrict__ to,
+                                                               uint32_t n_slots, uint32_t* __restrict__ sync) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (n_blocks + 1023u) / 1024u;
+    const uint32_t lo = t * per, hi = min(lo + per, n_blocks);
+    uint32_t sum = 0u;
+    for (uint32_t k = lo; k < hi; ++k) sum += counts[k];
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0u) {
+        uint32_t acc = 0u;
+        for (uint32_t k = 0; k < 1024u; ++k) { uint32_t v = part[k]; part[k] = acc; acc += v; }
+        counts[n_blocks] = acc;
+        sync[RT_LIVE_SLOTS] = acc;
+    }
+    __syncthreads();
+    uint32_t acc = part[t];
+    for (uint32_t k = lo; k < hi; ++k) { uint32_t v = counts[k]; counts[k] = acc; acc += v; }
+    __syncthreads();
+    const uint32_t total = counts[n_blocks];
+    const uint32_t n2 = RT_COMPACT_SLOTS(total, n_slots);
+    for (uint32_t s = total + t; s < n2; s += 1024u) to[(size_t)n2 + s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // plane 1
+}
+__global__ void __launch_bounds__(256) rt_compact_move_kernel(PathPool pool, const uint32_t* __restrict__ offsets, float4* __restrict__ to) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    float4 p1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (s < pool.n_slots) p1 = QP(pool, 1, s);
+    const bool holds = (__float_as_uint(p1.w) & DEPTH_MASK) != 0u;
+    __shared__ uint32_t wave_n[4];
+    const unsigned long long m = __ballot(holds);
+    if ((threadIdx.x & 63u) == 0u) wave_n[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (!holds) return;
+    uint32_t rank = (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63u)) - 1ull));
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) rank += wave_n[w];
+    const size_t d = (size_t)offsets[blockIdx.x] + rank, n = RT_COMPACT_SLOTS(offsets[gridDim.x], pool.n_slots);
+    to[d] = QP(pool, 0, s);
+    to[n + d] = p1;
+    to[2 * n + d] = QP(pool, 2, s);
+    to[3 * n + d] = QP(pool, 3, s); // a slot on hold keeps its settled hit
+    if (__float_as_uint(p1.w) & DEPTH_HAS_COLOR) to[4 * n + d] = QP(pool, 4, s);
 }
 
 // accum[pixel] (+)= radiance of the pixel's paths of this batch, added in column order like the sample loop of draw!
@@ -1724,6 +1783,12 @@ extern "C" void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, cons
 }
 extern "C" void rt_launch_redo(const DevScene* S, const PathPool* pool, uint32_t* d_sync, hipStream_t stream) {
     hipLaunchKernelGGL(rt_redo_kernel, dim3(256), dim3(256), 0, stream, *S, *pool, d_sync);
+}
+extern "C" void rt_launch_compact(const PathPool* from, float4* to, uint32_t* d_counts, uint32_t* d_sync, hipStream_t stream) {
+    const uint32_t n_blocks = (from->n_slots + 255u) / 256u;
+    hipLaunchKernelGGL(rt_compact_count_kernel, dim3(n_blocks), dim3(256), 0, stream, *from, d_counts);
+    hipLaunchKernelGGL(rt_compact_scan_kernel, dim3(1), dim3(1024), 0, stream, d_counts, n_blocks, to, from->n_slots, d_sync);
+    hipLaunchKernelGGL(rt_compact_move_kernel, dim3(n_blocks), dim3(256), 0, stream, *from, d_counts, to);
 }
 extern "C" void rt_launch_sum(const RtRenderParams* P, const float4* d_radiance, float* d_accum, int first_batch, hipStream_t stream) {
     hipLaunchKernelGGL(rt_sum_kernel, dim3((P->n_pixels + 255u) / 256u), dim3(256), 0, stream, *P, d_radiance, d_accum, first_batch);

@@ -119,6 +119,10 @@ def test_edge_cases(scenes, monkeypatch):
         assert st.paths == 150 * 110 * 5
     monkeypatch.delenv("RT_AMD_SLOTS")
     monkeypatch.delenv("RT_AMD_RADIANCE_MIB")
+    monkeypatch.setenv("RT_AMD_NO_COMPACT", "1")     # moving the last live slots together only changes where a path is kept
+    img, _ = dev.render(cam, pat, bg, 150, 110)
+    np.testing.assert_array_equal(bits(img), bits(big))
+    monkeypatch.delenv("RT_AMD_NO_COMPACT")
     monkeypatch.setenv("RT_AMD_NO_REGROUP", "1")     # material regrouping only changes which lane shades which slot
     img, _ = dev.render(cam, pat, bg, 40, 24)
     np.testing.assert_array_equal(bits(img), bits(want))
