@@ -163,7 +163,13 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(pmc):
                 with open(pmc) as f:
-                    roofline["traffic"] = json.load(f).get(args.scene)
+                    prof = json.load(f)
+                roofline["traffic"] = prof.get(args.scene)
+                # from the same committed profile (PMC passes over one frame): how busy the vector ALUs were and how many
+                # of the 64 lanes of an instruction did work -- the hardware-side reading of a VALU-bound kernel
+                if args.scene + "_valu_busy" in prof:
+                    roofline["valu_busy_profiled"] = prof[args.scene + "_valu_busy"]
+                    roofline["lanes_active_profiled"] = prof[args.scene + "_lanes_active"]
         line["roofline"] = roofline
         line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

@@ -40,5 +40,9 @@ if "extend" in pmc and "FETCH_SIZE" in pmc["extend"]:
     cur = json.load(open(path)) if os.path.exists(path) else {}
     cur[scene] = per_launch
     cur[scene + "_note"] = "bytes per rt_extend_kernel launch: (2*FETCH_SIZE + WRITE_SIZE) KB over %d launches, %s" % (e["dispatches"], tag)
+    # issue-side view of the same kernel: share of SIMD cycles with a VALU instruction in flight, and lanes active in it
+    if all(k in e for k in ("SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE")):
+        cur[scene + "_valu_busy"] = 4.0 * e["SQ_ACTIVE_INST_VALU"] / (1024.0 * e["GRBM_GUI_ACTIVE"] / 8.0)
+        cur[scene + "_lanes_active"] = e["SQ_THREAD_CYCLES_VALU"] / e["SQ_ACTIVE_INST_VALU"] / 64.0
     json.dump(cur, open(path, "w"), indent=1)
     print("HBM bytes per extend launch: %.1f MB" % (per_launch / 1e6))
