@@ -149,7 +149,7 @@ int fill_params(const float background[3], int width, int height, int max_depth,
     P->seed32 = fold_seed(seed);
     P->background[0] = background[0]; P->background[1] = background[1]; P->background[2] = background[2];
     P->image_floats = (size_t)3 * (size_t)width * (size_t)height;
-    P->leaf_threshold = (uint32_t)env_int("RT_AMD_LEAF_THRESHOLD", 32);
+    P->leaf_threshold = (uint32_t)env_int("RT_AMD_LEAF_THRESHOLD", 24);
     P->blocked_threshold = (uint32_t)env_int("RT_AMD_BLOCKED_THRESHOLD", 12);
     P->fetch_threshold = (uint32_t)env_int("RT_AMD_FETCH_THRESHOLD", 28);
     P->step_dropout = (uint32_t)env_int("RT_AMD_STEP_DROPOUT", 12);

@@ -16,7 +16,7 @@ struct RtCameraDev { // same field order as rtCamera (src/camera.jl:3-14)
 #define RT_DISP_UNIT 256u  // consecutive paths dealt to one dispenser
 #define RT_DISP_BASE 64u   // first dispenser word in the sync array
 #define RT_DISP_STRIDE 32u // words between dispensers (128 bytes)
-#define RT_SLOT_DISP 64u   // slot dispensers of the extend kernel (each hands out one contiguous share of the slots)
+#define RT_SLOT_DISP 128u  // slot dispensers of the extend kernel (each hands out one contiguous share of the slots)
 #define RT_SLOT_DISP_BASE (RT_DISP_BASE + RT_DISP_MAX * RT_DISP_STRIDE)
 #define RT_REDO_COUNT (RT_SLOT_DISP_BASE + RT_SLOT_DISP * RT_DISP_STRIDE) // entries in PathPool::redo; + 1: finished workgroups of rt_redo_kernel
 #define RT_TAIL_FLAG (RT_REDO_COUNT + 2u)  // set once a workgroup found no unstarted path left: slots now only run dry

@@ -1151,7 +1151,7 @@ __device__ __forceinline__ void camera_ray(const RtCameraDev& cam, const float* 
 #define HIT_MISS 6u
 #define HIT_WAIT 7u                  // shade kernel: the slot waits for rt_redo_kernel, nothing to shade yet
 #define RANK_SETTLED 0x80000000u     // bit of the rank word of a hit record: rt_redo_kernel has settled the hit
-#define EXTEND_CHUNK 256u
+#define EXTEND_CHUNK 128u
 
 // random-number key of the path at pixel r (row-major) and column kk of the batch; returns the pattern column
 __device__ __forceinline__ int path_key(const RtRenderParams& P, uint32_t kk, uint32_t r, RngKey& key) {
