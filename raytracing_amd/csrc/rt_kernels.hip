@@ -1359,13 +1359,26 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
         // ---- hot loop: step through nodes until `step_dropout` more lanes have left it
         {
             const uint32_t floor_lanes = ns > P.step_dropout ? ns - P.step_dropout : 1u;
+            // t_max does not change in this loop: widened once like the far distance of a box (node_test), and held
+            // against the entry distance by a comparison of its own
+            const float t_far = __builtin_fmaf(fabsf(t_max), 4.8e-7f, t_max);
+            const unsigned long long m_busy = __builtin_amdgcn_ballot_w64(busy);
+            uint32_t n_step;
             bool stepping = ws;
             do {
                 if (stepping) {
                     if (COUNT) { cnt.nodes++; cnt.node_waves += first_active_lane(); }
-                    bool hit;
-                    uint32_t link;
-                    node_test(S, R, t_min, t_max, node, hit, link);
+                    // node_test() with t_max taken out of the min
+                    const uint4 q = S.nodes[node];
+                    const v2h hx = __builtin_bit_cast(v2h, q.x), hy = __builtin_bit_cast(v2h, q.y), hz = __builtin_bit_cast(v2h, q.z);
+                    const float ax = __builtin_fmaf((float)hx.x, R.i.x, R.cn.x), fx = __builtin_fmaf((float)hx.y, R.i.x, R.cf.x);
+                    const float ay = __builtin_fmaf((float)hy.x, R.i.y, R.cn.y), fy = __builtin_fmaf((float)hy.y, R.i.y, R.cf.y);
+                    const float az = __builtin_fmaf((float)hz.x, R.i.z, R.cn.z), fz = __builtin_fmaf((float)hz.y, R.i.z, R.cf.z);
+                    const float tnear = fmaxf(fmaxf(ax, ay), fmaxf(az, t_min));
+                    float tfar = fminf(fminf(fx, fy), fz);
+                    tfar = __builtin_fmaf(fabsf(tfar), 4.8e-7f, tfar);
+                    const bool hit = tnear <= tfar && tnear <= t_far;
+                    const uint32_t link = q.w;
                     // branch-free bookkeeping: where the walk goes on, and the leaf queue (a shift register)
                     const bool is_leaf = (int32_t)link < 0;
                     const bool push = hit && is_leaf;
@@ -1374,9 +1387,15 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                     q1 = push ? q0 : q1;
                     q0 = push ? (link & ~RT_NODE_LEAF) : q0;
                     nq += push ? 1u : 0u;
-                    stepping = node != end && nq < LEAF_QUEUE && !(NESTED && push && (link & RT_LEAF_INSTANCE));
                 }
-            } while ((uint32_t)__popcll(__ballot(stepping)) >= floor_lanes);
+                // from the lane's state (the same test as `ws` above), each comparison voted on its own: the votes are
+                // then the comparisons' lane masks themselves, combined by scalar instructions
+                const bool more = node != end, room = nq < LEAF_QUEUE;
+                const bool enter = NESTED && nq != 0u && (q0 & RT_LEAF_INSTANCE);
+                stepping = busy && more && room && !enter;
+                n_step = (uint32_t)__popcll(m_busy & __builtin_amdgcn_ballot_w64(more) & __builtin_amdgcn_ballot_w64(room) &
+                                            ~(NESTED ? __builtin_amdgcn_ballot_w64(enter) : 0ull));
+            } while (n_step >= floor_lanes);
         }
     }
     if (COUNT) {
