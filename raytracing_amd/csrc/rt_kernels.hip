@@ -1444,6 +1444,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
     __shared__ uint32_t hist[8], cursor[8];
     __shared__ uint16_t order[SHADE_BLOCK];
     __shared__ float4 hits[SHADE_BLOCK];  // per slot of the block: {t, prim, side|xform, type} after the media
+    __shared__ float4 ray0[SHADE_BLOCK], ray1[SHADE_BLOCK], ray2[SHADE_BLOCK]; // planes 0-2 of the block's slots, for phase 2
     __shared__ uint32_t block_alive, block_need, block_base, block_disp;
     const uint32_t t = threadIdx.x;
     const uint32_t base = blockIdx.x * SHADE_BLOCK;
@@ -1457,8 +1458,10 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
     if (base + t < pool.n_slots) {
         float4 q1 = QP(pool, 1, base + t), q2 = QP(pool, 2, base + t), q4 = QP(pool, 3, base + t);
         int depth0 = (int)(__float_as_uint(q1.w) & DEPTH_MASK);
+        ray1[t] = q1; ray2[t] = q2;
         if (depth0 > 0) {
             const float4 q0 = QP(pool, 0, base + t);
+            ray0[t] = q0;
             const f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q1.x, q1.y, q1.z);
             // rt_extend_kernel found the closest surface of the device tree.  Here, with every lane holding a ray, that
             // hit is held against the boxes of the reference's trees (ref_reaches).  In the rare case that it does not
@@ -1509,7 +1512,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
     uint32_t slot = base + mine;
     bool valid = slot < pool.n_slots;
     float4 q1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q0 = q1, q2 = q1;
-    if (valid) { q1 = QP(pool, 1, slot); q0 = QP(pool, 0, slot); q2 = QP(pool, 2, slot); }
+    if (valid) { q1 = ray1[mine]; q0 = ray0[mine]; q2 = ray2[mine]; } // ray0 is only defined (and only used) for slots that hold a ray
     const uint32_t depth_word = __float_as_uint(q1.w);
     int depth = (int)(depth_word & DEPTH_MASK);
     bool done = false, cont = false;
