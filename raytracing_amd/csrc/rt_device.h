@@ -10,10 +10,13 @@
 //             whose box is hit continues at node+1 (its first child), one that is missed at its skip link (the next
 //             node in pre-order that is not a descendant); a leaf always continues at node+1.  The walk of a tree is
 //             over when it reaches the index one past the tree's last node.  One tree covers every surface of the
-//             SceneManager, a second one the constant media, and the nested trees (Transform{BVHTree}) follow.  The
-//             whole array exists eight times, once per octant of ray directions, with the children of every node
-//             ordered near side first for that octant: layout o occupies nodes [o * n_nodes, (o + 1) * n_nodes) and
-//             its skip links stay inside it; roots are given relative to the layout.
+//             SceneManager, and the nested trees kept as instances (Transform{BVHTree}) follow; the constant media
+//             are a list (`media`), not a tree.  The whole array exists eight times, once per octant of ray
+//             directions, with the children of every node ordered near side first for that octant: layout o occupies
+//             nodes [o * n_nodes, (o + 1) * n_nodes) and its skip links stay inside it; roots are given relative to
+//             the layout.  A second set of eight layouts (same trees, looser leaf boxes) may follow, see far_set.
+//   prim_box: the boxes of the reference's own trees per primitive, for the test the reference makes before it
+//             reaches a primitive (see RT_BOX_OUTER / RT_BOX_INNER).
 //   prims   : 48 B per primitive = 3 x uint4: {head, material, rank, g0}, {g1..g4}, {g5..g8}
 //             head = kind (bits 0-3) | medium flag (bit 4) | index field (bits 8-31):
 //             transform index + 1 (0 = none), or for triangles the attribute record index.

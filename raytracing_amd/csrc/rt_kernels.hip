@@ -5,8 +5,9 @@
 // Arithmetic contract: every primitive intersection, hit completion and scatter formula is evaluated in the
 // operation order of the reference's Float32 code with IEEE add/mul/div/sqrt and NO fused multiply-add (this
 // file is compiled with -ffp-contract=off), so hit distances, primitive choices and scattered rays are
-// bit-identical to a plain CPU evaluation of the same formulas.  Only the BVH box test, which merely culls,
-// uses reciprocal multiplication, and it is widened so that it never rejects a box the exact test accepts.
+// bit-identical to a plain CPU evaluation of the same formulas.  Only the box test of the device tree, which merely
+// culls, uses reciprocal multiplication, and it is widened so that it never rejects a box the exact test accepts;
+// what the reference's own box tests cull on top of that is taken away again, exactly (ref_reaches).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
