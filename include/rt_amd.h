@@ -259,6 +259,15 @@ typedef struct rtLayout {
 int rt_scene_layout(const rtSceneDesc* desc, rtLayout* info, uint32_t* nodes, size_t node_capacity,
                     int32_t* prim_top, size_t prim_capacity);
 
+/* A scene description in one binary file.  The reference has no scene files -- its scenes are Julia functions
+ * (the files of samples/, registered in scenes.jl:8-11) -- this is the data they hand to draw!: the tables and the trees of an
+ * rtSceneDesc, so that a host other than the reference's Julia code, or a later run, can pass a scene to
+ * rt_scene_create without rebuilding it.  rt_scene_desc_load allocates the description and everything it points to;
+ * release it with rt_scene_desc_free (after rt_scene_create, which copies what it needs). */
+int rt_scene_desc_save(const rtSceneDesc* desc, const char* path);
+int rt_scene_desc_load(const char* path, rtSceneDesc** out);
+void rt_scene_desc_free(rtSceneDesc* desc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,7 @@ The CPU branch of the reference (gpu=false) is the reference's own Julia code an
 reimplemented here: this package renders on the MI355X or not at all.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -28,6 +29,16 @@ def _pattern(pattern):
     p = np.asarray(pattern, dtype=F)
     assert p.ndim == 2 and p.shape[0] == 2, "pattern must be 2 x N"
     return np.ascontiguousarray(p.T).reshape(-1), p.shape[1]
+
+
+def save_scene(path, world):
+    """Writes the scene description of `world` (its tables and the trees build_bvh makes of it: what rt_scene_create
+    takes) to one binary file (rt_scene_desc_save); DeviceScene.from_file(path) renders it without the world list."""
+    world = list(world)
+    bvh = build_bvh_scene(SceneManager(world))
+    desc, keep = flatten_scene(world, bvh)
+    ffi.check(ffi.lib().rt_scene_desc_save(C.byref(desc), os.fsencode(path)))
+    del keep
 
 
 def scene_layout(world):
@@ -62,6 +73,21 @@ class DeviceScene:
         self._keep = keep
         self.handle = C.c_void_p()
         ffi.check(ffi.lib().rt_scene_create(C.byref(desc), int(device), C.byref(self.handle)))
+
+    @classmethod
+    def from_file(cls, path, device=0):
+        """A scene written by save_scene (rt_scene_desc_load + rt_scene_create): no world list, no tree build."""
+        self = cls.__new__(cls)
+        self.world = self.scene_manager = self.bvh = self._keep = None
+        self.handle = C.c_void_p()
+        desc = C.POINTER(ffi.rtSceneDesc)()
+        L = ffi.lib()
+        ffi.check(L.rt_scene_desc_load(os.fsencode(path), C.byref(desc)))
+        try:
+            ffi.check(L.rt_scene_create(desc, int(device), C.byref(self.handle)))
+        finally:
+            L.rt_scene_desc_free(desc)
+        return self
 
     def close(self):
         if self.handle:

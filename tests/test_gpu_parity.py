@@ -329,6 +329,25 @@ def test_progressive_rendering_and_resume(scenes, tmp_path):
         next(dev.render_progressive(cam, pat, bg, W, H, passes=4, state=stored))
 
 
+@pytest.mark.parametrize("name", ["cornell_smoke_box", "cover2"])
+def test_scene_from_a_file_renders_the_same_picture(name, scenes, tmp_path):
+    """save_scene + DeviceScene.from_file (rt_scene_desc_save / rt_scene_desc_load): the picture of the scene that came
+    back from the file is, bit for bit, the picture of the scene it was written from"""
+    world, kw, dev, ref = scenes(name)
+    cam, bg = kw["camera"], kw["background"]
+    pat = rt.Halton_sequence32(6)
+    W, H = 56, 40
+    want, _ = dev.render(cam, pat, bg, W, H)
+    path = tmp_path / "scene.rtscene"
+    rt.save_scene(path, world)
+    loaded = rt.DeviceScene.from_file(path)
+    try:
+        got, _ = loaded.render(cam, pat, bg, W, H)
+    finally:
+        loaded.close()
+    np.testing.assert_array_equal(bits(got), bits(want))
+
+
 def test_device_output_stage_matches_host_quantisation(scenes):
     """rt_finalize_rgb8 (clamp01 + N0f8 on the device) == rt_finalize followed by the host quantisation"""
     import torch
