@@ -268,6 +268,13 @@ int rt_scene_desc_save(const rtSceneDesc* desc, const char* path);
 int rt_scene_desc_load(const char* path, rtSceneDesc** out);
 void rt_scene_desc_free(rtSceneDesc* desc);
 
+/* The tables of a NoiseTexture (Perlin3 constructors, src/perlin.jl:17-33): 256 unit vectors drawn as
+ * normalize(rand(Vec3, -1, 1)) (vector != 0) or 256 scalars in [0, 1) (vector == 0), then perm_y, perm_z and perm_x as
+ * three shuffles of 0..255, in that order.  The reference draws from Julia's unseeded global rand(); this draws from the
+ * stream the library's sample scenes use: draw k is pcg4d(k, 0x5CE7E5, seed), with k = *counter on entry; on return
+ * *counter is the index of the next unused draw (768 or 256 values + 765 shuffle draws later). */
+int rt_perlin_generate(uint32_t seed, uint64_t* counter, int32_t vector, rtPerlin* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -125,6 +125,7 @@ SYMBOLS = {
     "rt_scene_desc_save": (C.c_int, [C.POINTER(rtSceneDesc), C.c_char_p]),
     "rt_scene_desc_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(rtSceneDesc))]),
     "rt_scene_desc_free": (None, [C.POINTER(rtSceneDesc)]),
+    "rt_perlin_generate": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint64), C.c_int32, C.POINTER(rtPerlin)]),
     "rt_scene_layout": (C.c_int, [C.POINTER(rtSceneDesc), C.POINTER(rtLayout), C.POINTER(C.c_uint32), C.c_size_t,
                                   c_i32p, C.c_size_t]),
     "rt_bvh_build": (C.c_int, [C.c_int, c_f32p, c_i32p, c_f32p, c_i32p, c_i32p, c_u8p]),

@@ -70,21 +70,19 @@ class ImageTexture(Texture):
 
 
 class Perlin3:
-    """src/perlin.jl:5-33: 256 normalised random vectors (or scalars) and three permutations of 0..255."""
+    """src/perlin.jl:5-33: 256 normalised random vectors (or scalars) and three permutations of 0..255, drawn by the
+    library (rt_perlin_generate) from the position `rng` (a scenes.SceneRng) stands at; `rng` moves past the draws."""
 
     def __init__(self, rng, vector=True, point_count=256):
+        import ctypes as C
+        from . import _ffi as ffi
         assert point_count == 256
         self.vector = vector
-        self.random = np.zeros((point_count, 3), dtype=F)
-        for i in range(point_count):
-            if vector:  # normalize(rand(Vec3{F}, -1, 1)), src/perlin.jl:18
-                v = Vec3(rng.rand32() * F(2) + F(-1), rng.rand32() * F(2) + F(-1), rng.rand32() * F(2) + F(-1))
-                self.random[i] = normalize(v)
-            else:
-                self.random[i, 0] = rng.rand32()
-        self.perm_y = rng.shuffle(list(range(point_count)))
-        self.perm_z = rng.shuffle(list(range(point_count)))
-        self.perm_x = rng.shuffle(list(range(point_count)))
+        table, ctr = ffi.rtPerlin(), C.c_uint64(rng.ctr)
+        ffi.check(ffi.lib().rt_perlin_generate(rng.seed, C.byref(ctr), int(bool(vector)), C.byref(table)))
+        rng.ctr = ctr.value
+        self.random = np.array(table.ranvec, dtype=F).reshape(point_count, 3)
+        self.perm_x, self.perm_y, self.perm_z = list(table.perm_x), list(table.perm_y), list(table.perm_z)
 
 
 class NoiseTexture(Texture):
