@@ -1,0 +1,138 @@
+"""Random scenes against the oracle: every kind of object, wrapper, material and texture the path supports, thrown
+together with a seeded generator -- closest hits of fixed rays and whole images must be identical bit for bit.
+
+One known exception, kept visible here: a camera 30 or 400 scene sizes away.  There the reference's sphere test
+(src/sphere.jl:45-65) has lost its digits -- the discriminant's rounding noise, 7e-7 |o - c|^2 |d|^2, exceeds r^2 |d|^2 --
+and reports hits up to 1e-3 |o - c| in front of the sphere's own leaf box.  Which of two such hits the reference
+keeps then depends on the order in which its trees meet them (the later one's box is culled by the earlier hit's
+distance, src/BVH.jl:22-53 with src/bounding_box.jl:20-67), and the device tree culls by the same kind of bound in
+its own order.  About one such ray in 70 000 comes out differently (3 % of these scenes differ in one ray or
+pixel); the test bounds that instead of hiding the scenes."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import raytracing_amd as rt
+from raytracing_amd.scene_manager import build_bvh
+from raytracing_amd.scenes import SceneRng
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=F).view(np.uint32)
+
+
+def random_scene(seed):
+    g = np.random.default_rng(seed)
+    noise = SceneRng(seed)
+    # every third scene at another scale (0.01 .. 100) and / or seen from far away (up to 400 scene sizes): small
+    # things against the fixed t_min, thin boxes whose planes round together, node boxes built for a wider reach
+    S = float(10.0 ** g.uniform(-2, 2)) if seed % 3 == 0 else 1.0
+    far = float((1, 30, 400)[g.integers(0, 3)]) if seed % 3 == 1 else 1.0
+    r = lambda lo, hi: float(g.uniform(lo, hi))          # plain number
+    u = lambda lo, hi: S * float(g.uniform(lo, hi))      # length
+    vec = lambda lo, hi: rt.Vec3(u(lo, hi), u(lo, hi), u(lo, hi))
+    col = lambda lo, hi: rt.Vec3(r(lo, hi), r(lo, hi), r(lo, hi))
+
+    def texture():
+        k = g.integers(0, 6)
+        if k == 0:
+            return rt.CheckerTexture(col(0, 1), col(0, 1))
+        if k == 1:
+            return rt.NoiseTexture(r(0.5, 4.0) / S, noise, vector=bool(g.integers(0, 2)))
+        if k == 2:
+            return rt.ImageTexture(g.integers(0, 256, (int(g.integers(1, 9)), int(g.integers(1, 9)), 3)).astype(np.uint8))
+        return rt.SolidColor(col(0.1, 1))
+
+    def material():
+        k = g.integers(0, 10)
+        if k < 4:
+            return rt.Material(rt.Lambertian, texture())
+        if k < 6:
+            return rt.Material(rt.Metal, col(0.3, 1), r(0, 0.6))
+        if k < 8:
+            return rt.Material(rt.Dielectric, r(1.1, 2.0))
+        return rt.Material(rt.Emissive, col(0.5, 6))
+
+    def sphere():
+        return rt.Sphere(vec(-10, 10), u(0.2, 3.0), material())
+
+    def box():
+        p = vec(-10, 10)
+        return rt.Box(p, p + vec(0.3, 4.0), material())
+
+    def rect():
+        cls = (rt.xy_rect, rt.xz_rect, rt.yz_rect)[g.integers(0, 3)]
+        a, b = u(-10, 8), u(-10, 8)
+        return cls(a, a + u(0.5, 8), b, b + u(0.5, 8), u(-10, 10), material())
+
+    def xform():
+        return rt.affine(rt.RotY(math.radians(r(-180, 180))), [u(-6, 6), u(-6, 6), u(-6, 6)])
+
+    world = []
+    for _ in range(int(g.integers(4, 30))):
+        k = g.integers(0, 12)
+        if k < 3:
+            world.append(sphere())
+        elif k == 3:
+            c = vec(-8, 8)
+            world.append(rt.MovingSphere(c, c + vec(-1, 1), 0.0, 1.0, u(0.3, 2.0), material()))
+        elif k < 6:
+            world.append(rect())
+        elif k < 8:
+            world.append(box())
+        elif k == 8:
+            world.append(rt.Transform((sphere, box, rect)[g.integers(0, 3)](), xform()))
+        elif k == 9:
+            boundary = (sphere, box)[g.integers(0, 2)]()
+            if g.integers(0, 2) and isinstance(boundary, rt.Box):
+                boundary = rt.Transform(boundary, xform())
+            world.append(rt.ConstantMedium(boundary, r(0.05, 1.5) / S, col(0, 1)))
+        elif k == 10:
+            members = [rt.Sphere(vec(-3, 3), u(0.1, 0.8), material()) for _ in range(int(g.integers(2, 40)))]
+            world.append(rt.Transform(build_bvh(members), xform()))
+        else:
+            world.append(rt.ConstantMedium(rt.Sphere(rt.Vec3(0), u(30, 60), rt.Material(rt.Dielectric, 1.5)), r(0.001, 0.02) / S, col(0.5, 1)))
+    eye = vec(-25, 25) * F(far)
+    cam = rt.Camera(eye, eye - vec(-3, 3), rt.Vec3(0, 1, 0), r(20, 90) / min(far, 40.0), 1.25,
+                    u(0, 0.5) if g.integers(0, 2) else 0.0, u(5, 30) * far, 0.0, 1.0)
+    bg = col(0, 1) if g.integers(0, 3) else rt.Vec3(0)
+    return world, cam, bg
+
+
+# RT_AMD_FUZZ_SCENES=N widens the sweep (the default keeps the suite short)
+@pytest.mark.parametrize("seed", range(1, 1 + int(os.environ.get("RT_AMD_FUZZ_SCENES", "24"))))
+def test_random_scene(seed):
+    world, cam, bg = random_scene(seed)
+    far_camera = seed % 3 == 1      # see the module comment
+    W, H = 40, 32
+    pat = rt.Halton_sequence32(6)
+    ref = O.OracleScene(world)
+    dev = rt.DeviceScene(world)
+    try:
+        rays = O.primary_rays(cam, W, H, 48, 40, time=0.37)
+        g = np.random.default_rng(1000 + seed)
+        a = ref.trace_rays(rays)
+        pts = rays[:, :3] + rays[:, 3:6] * np.where(np.isfinite(a["t"]), a["t"] * 0.95, 1.0)[:, None]
+        sec = np.concatenate([pts, g.normal(size=(len(rays), 3)), g.uniform(0, 1, (len(rays), 1))], axis=1).astype(F)
+        for batch in (rays, sec):
+            a, b = ref.trace_rays(batch), dev.trace_rays(batch)
+            same = (a["prim_id"] == b["prim_id"]) & (a["sub_id"] == b["sub_id"]) & (bits(a["t"]) == bits(b["t"]))
+            if far_camera:
+                assert (~same).sum() <= 8      # of 1920 rays
+            else:
+                assert same.all()
+            for field in ("normal", "uv"):
+                np.testing.assert_array_equal(bits(a[field])[same], bits(b[field])[same])
+            np.testing.assert_array_equal(a["front"][same], b["front"][same])
+        img, st = dev.render(cam, pat, bg, W, H)
+        differing = (bits(img) != bits(ref.render(cam, pat, bg, W, H))).any(axis=2).sum()
+        assert differing <= (8 if far_camera else 0)      # of 1280 pixels
+        assert st.paths == W * H * 6
+    finally:
+        dev.close()
