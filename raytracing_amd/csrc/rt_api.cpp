@@ -38,7 +38,7 @@ struct rtScene {
     DevScene dev{};
     HostScene host;              // the staged scene: its leaves and tables stay, for node sets built for a wider reach
     uint4* d_nodes = nullptr;    // room for two node sets
-    void* buffers[16] = {nullptr};
+    void* buffers[24] = {nullptr};
     int n_buffers = 0;
     // scratch owned by the handle, grown on demand
     float* d_pattern = nullptr; size_t pattern_cap = 0;
@@ -195,6 +195,7 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     if (st == RT_OK) st = upload(s, H.prims, &s->dev.prims);
     if (st == RT_OK) st = upload(s, H.prim_inv, &s->dev.prim_inv);
     if (st == RT_OK) st = upload(s, H.prim_box, &s->dev.prim_box);
+    if (st == RT_OK) st = upload(s, H.bucket_base, &s->dev.bucket_base);
     if (st == RT_OK) st = upload(s, H.xforms, &s->dev.xforms);
     if (st == RT_OK) st = upload(s, H.materials, &s->dev.materials);
     if (st == RT_OK) st = upload(s, H.textures, &s->dev.textures);
@@ -225,6 +226,7 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     s->dev.surface_root = H.surface_root;
     s->dev.surface_size = H.surface_size;
     s->dev.n_media = (uint32_t)H.media.size();
+    s->dev.n_buckets = (uint32_t)H.bucket_base.size();
     s->dev.nested = H.nested ? 1u : 0u;
     s->dev.textured = H.textured ? 1u : 0u;
     *out = s;

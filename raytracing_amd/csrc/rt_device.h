@@ -70,6 +70,7 @@ struct DevScene {
     const float* perlin_vec;     // 768 floats per perlin
     const int32_t* perlin_perm;  // 768 ints per perlin (x, y, z)
     const uint32_t* media;       // the constant media (primitive indices) in descending rank
+    const uint32_t* bucket_base; // lowest rank of every type group of the SceneManager, in its order (descending ranks)
     const int32_t* prim_top;     // per primitive: position in the world vector (reported prim_id)
     const int32_t* prim_sub;     // per primitive: reported sub id base (triangle id / nested object index)
     uint32_t n_nodes, n_prims; // n_nodes: nodes per octant layout
@@ -83,6 +84,7 @@ struct DevScene {
     uint32_t nested;       // 1 if the scene holds nested trees (Transform{BVHTree})
     uint32_t textured;     // 1 if any texture is not a SolidColor
     uint32_t n_media;      // entries in `media`
+    uint32_t n_buckets;    // entries in `bucket_base`
 };
 
 #endif

@@ -360,9 +360,12 @@ __device__ __forceinline__ void box_frame(const DevScene& S, f3 o, f3 d, BoxRay&
 // non-finite or denormal distance, which fails these comparisons) goes through the reference's sequence itself.
 // MISSES: the caller's boxes are often missed outright (the candidates of a walk, as opposed to the box of a hit that
 // was found): an interval that is empty by more than the error of the fast distances is turned down on the fast path too.
+// near_up (when the test passes): a distance not below the one at which the reference finds the ray entering the box
+// (its t_min after the three axes), exact where the reference's own sequence ran.
 template <bool MISSES>
-__device__ __forceinline__ bool ref_box_pass(float4 b0, float4 b1, f3 o, f3 d, float t_min, float t_max) {
+__device__ __forceinline__ bool ref_box_pass(float4 b0, float4 b1, f3 o, f3 d, float t_min, float t_max, float& near_up) {
     const f3 mn = mk3(b0.x, b0.y, b0.z), mx = mk3(b0.w, b1.x, b1.y);
+    near_up = t_min;
     if (MISSES && t_min == 0.001f) {
         // A ray that starts inside the box, further than g from every plane (the ray of nearly every path inside the
         // box of a scene-wide medium): per axis one plane lies behind the origin and one ahead, |plane - origin| > g as
@@ -390,7 +393,7 @@ __device__ __forceinline__ bool ref_box_pass(float4 b0, float4 b1, f3 o, f3 d, f
         const bool apart = (__builtin_fmaf(-SEP, fmaxf(fabsf(nx.x), fabsf(nx.y)), nx.y - nx.x) > 0.0f) &&
                            (__builtin_fmaf(-SEP, fmaxf(fabsf(ny.x), fabsf(ny.y)), ny.y - ny.x) > 0.0f) &&
                            (__builtin_fmaf(-SEP, fmaxf(fabsf(nz.x), fabsf(nz.y)), nz.y - nz.x) > 0.0f);
-        if (cross && apart && t_min > 1e-30f) return true;
+        if (cross && apart && t_min > 1e-30f) { near_up = fmaxf(fmaxf(lx, ly), fmaxf(lz, t_min)); return true; }
     }
     float lo, hi;
     lo = (mn.x - o.x) / d.x; hi = (mx.x - o.x) / d.x;
@@ -407,27 +410,85 @@ __device__ __forceinline__ bool ref_box_pass(float4 b0, float4 b1, f3 o, f3 d, f
     if (lo > hi) { float w = lo; lo = hi; hi = w; }
     if (hi < t_max) t_max = hi;
     if (lo > t_min) t_min = lo;
+    near_up = t_min;
     return !(t_max <= t_min);
 }
+template <bool MISSES>
+__device__ __forceinline__ bool ref_box_pass(float4 b0, float4 b1, f3 o, f3 d, float t_min, float t_max) {
+    float unused;
+    return ref_box_pass<MISSES>(b0, b1, o, d, t_min, t_max, unused);
+}
 // Does the reference reach primitive `prim` with the ray (o, d) as cast?  xf: index + 1 of the Transform around the
-// nested tree the primitive belongs to, if any.  t_max is the bound the ray was cast with: the reference tests with the
-// closest distance found so far, which differs from it only for boxes that lie behind that distance anyway.
+// nested tree the primitive belongs to, if any.  t_max: the bound the reference has at that moment -- the one the ray
+// was cast with when the question is only whether the box is passed at all (hit_stands says when that is enough), the
+// closest distance so far of the primitive's tree when the reference's sequence is played (surface_again).
 // b0, b1: the first two words of the primitive's record in prim_box (loaded by the caller, as early as it can)
+// near_up: upper bound of the distance at which the ray enters the innermost of those boxes.  skip_outer: the outer box
+// is known to have been passed (the walk is already inside that nested tree).
 template <bool MISSES>
 __device__ __forceinline__ bool ref_reaches(const DevScene& S, uint32_t prim, float4 b0, float4 b1, uint32_t xf, f3 o, f3 d,
-                                            float t_min, float t_max) {
+                                            float t_min, float t_max, float& near_up, bool skip_outer = false) {
     const float4* b = S.prim_box + 4u * prim;
     const uint32_t flags = __float_as_uint(b1.z);
-    if ((flags & RT_BOX_OUTER) && !ref_box_pass<MISSES>(b0, b1, o, d, t_min, t_max)) return false;
+    near_up = t_min;
+    if ((flags & RT_BOX_OUTER) && !(skip_outer && (flags & RT_BOX_INNER)) && !ref_box_pass<MISSES>(b0, b1, o, d, t_min, t_max, near_up)) return false;
     if (flags & RT_BOX_INNER) {
         if (xf) { // src/transform.jl:104-105
             const float* T = S.xforms + 24u * (xf - 1u) + 12;
             f3 no = apply_point(T, o), nd = apply_vec(T, d);
             o = no; d = nd;
         }
-        if (!ref_box_pass<MISSES>(b[2], b[3], o, d, t_min, t_max)) return false;
+        float inner;
+        if (!ref_box_pass<MISSES>(b[2], b[3], o, d, t_min, t_max, inner)) return false;
+        near_up = fmaxf(near_up, inner);
     }
     return true;
+}
+template <bool MISSES>
+__device__ __forceinline__ bool ref_reaches(const DevScene& S, uint32_t prim, float4 b0, float4 b1, uint32_t xf, f3 o, f3 d,
+                                            float t_min, float t_max) {
+    float unused;
+    return ref_reaches<MISSES>(S, prim, b0, b1, xf, o, d, t_min, t_max, unused);
+}
+// t_min as the reference's box test leaves it after the three axes (the distance at which the ray enters the box, or
+// the t_min it came with), for a box the test passes
+__device__ __forceinline__ float ref_box_near(float4 b0, float4 b1, f3 o, f3 d, float t_min) {
+    float lo, hi;
+    lo = (b0.x - o.x) / d.x; hi = (b0.w - o.x) / d.x;
+    if (lo > hi) lo = hi;
+    if (lo > t_min) t_min = lo;
+    lo = (b0.y - o.y) / d.y; hi = (b1.x - o.y) / d.y;
+    if (lo > hi) lo = hi;
+    if (lo > t_min) t_min = lo;
+    lo = (b0.z - o.z) / d.z; hi = (b1.y - o.z) / d.z;
+    if (lo > hi) lo = hi;
+    if (lo > t_min) t_min = lo;
+    return t_min;
+}
+// Does the hit `t` of primitive `prim` stand as the reference's closest hit, given that it is the closest of all the
+// hits the primitives report?  It does if the reference reaches the primitive and the hit does not lie in front of the
+// primitive's own box: then whatever the reference met before lies further away and cannot have culled that box, and
+// nothing met later is closer.  A sphere's hit can lie in front of its box (the sphere test reports points up to
+// sqrt(1.4e-6) |o - c| off the sphere); the other shapes report points of their box up to the last bit.
+__device__ __forceinline__ bool hit_stands(const DevScene& S, uint32_t prim, uint32_t xf, f3 o, f3 d, float t_min, float t_max, float t) {
+    const float4* b = S.prim_box + 4u * prim;
+    const uint32_t kind = S.prims[3u * prim].x & 15u;
+    float near_up;
+    if (!ref_reaches<false>(S, prim, b[0], b[1], xf, o, d, t_min, t_max, near_up)) return false;
+    if (!(kind <= DP_MOVING_SPHERE && t < near_up)) return true;
+    // in front of the upper bound: now the entry distances as the reference computes them (src/bounding_box.jl:20-67)
+    const uint32_t flags = __float_as_uint(b[1].z);
+    float near = t_min;
+    if (flags & RT_BOX_OUTER) near = ref_box_near(b[0], b[1], o, d, near);
+    if (flags & RT_BOX_INNER) {
+        if (xf) {
+            const float* T = S.xforms + 24u * (xf - 1u) + 12;
+            f3 no = apply_point(T, o), nd = apply_vec(T, d);
+            o = no; d = nd;
+        }
+        near = fmaxf(near, ref_box_near(b[2], b[3], o, d, t_min));
+    }
+    return !(t < near);
 }
 template <bool MISSES>
 __device__ __forceinline__ bool ref_reaches(const DevScene& S, uint32_t prim, uint32_t xf, f3 o, f3 d, float t_min, float t_max) {
@@ -731,29 +792,44 @@ struct WalkScene {
     const float4* prim_box;
     const float4* prim_inv;
     const float* xforms;
-    uint32_t n_nodes, surface_root, surface_size, far_set;
+    const uint32_t* bucket_base;
+    uint32_t n_nodes, surface_root, surface_size, far_set, n_buckets;
     float node_scale, inv_node_scale, cx, cy, cz, radius2;
 };
 __device__ __forceinline__ WalkScene walk_scene(const DevScene& S) {
-    return WalkScene{S.nodes, S.prims, S.prim_box, S.prim_inv, S.xforms, S.n_nodes, S.surface_root, S.surface_size, S.far_set,
-                     S.node_scale, S.inv_node_scale, S.centre[0], S.centre[1], S.centre[2], S.radius2};
+    return WalkScene{S.nodes, S.prims, S.prim_box, S.prim_inv, S.xforms, S.bucket_base, S.n_nodes, S.surface_root, S.surface_size,
+                     S.far_set, S.n_buckets, S.node_scale, S.inv_node_scale, S.centre[0], S.centre[1], S.centre[2], S.radius2};
 }
-// For a ray whose closest surface hit `best` the reference does not reach (ref_reaches; about one ray in a million):
-// the closest hit behind it that the reference does reach, or none.  The lane walks the surface tree again, on its own,
-// leaving out everything up to the hit that failed -- and again, should the next one fail too.  Kept out of line: the
-// callers are tuned for their common path and must not pay registers for this one.
-__device__ __forceinline__ Closest surface_again(WalkScene A, f3 o, f3 d, float time, float t_min, float t_hi, Closest best) {
-    DevScene S = {};
-    S.nodes = A.nodes; S.prims = A.prims; S.prim_box = A.prim_box; S.prim_inv = A.prim_inv; S.xforms = A.xforms;
-    S.n_nodes = A.n_nodes; S.surface_root = A.surface_root; S.surface_size = A.surface_size;
-    S.node_scale = A.node_scale; S.inv_node_scale = A.inv_node_scale;
-    S.far_set = A.far_set; S.centre[0] = A.cx; S.centre[1] = A.cy; S.centre[2] = A.cz; S.radius2 = A.radius2;
+// The hit the reference ends up with, found the way the reference finds it, over the whole scene (what surface_again
+// falls back to when its short list overflows).  The reference meets the primitives in a fixed order (rank, higher
+// first).  Inside one type group (one tree) the closest distance so far is t_max for the boxes on the way to a primitive
+// and for its own test, and a hit is taken if it is closer (src/BVH.jl:22-53); between the groups hit(::SceneManager)
+// (src/scene_manager.jl:40-52) hands on `closest_t`, which its reduction only sets when a later group's hit replaces the
+// one held -- the first group's own hit never becomes a bound.  So: again and again, the highest-ranked primitive below
+// the last one taken that the reference reaches and hits with the bound of its group -- one walk of the device tree
+// per hit the reference takes, a handful.  The device boxes hold every point at which their primitive can report a
+// hit, so dropping the boxes that begin behind the largest bound in play loses nothing.
+__device__ __forceinline__ uint32_t group_of(const DevScene& S, uint32_t rank) {
+    uint32_t g = 0u;
+    while (g + 1u < S.n_buckets && rank < S.bucket_base[g]) ++g;
+    return g;
+}
+__device__ __forceinline__ Closest reference_sequence(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_hi) {
     const f3 wo = o, wd = d; // the ray as cast
-    do {
-        const float floor_t = best.t;
-        const uint32_t floor_rank = best.rank;
-        best.t = INF; best.prim = 0xFFFFFFFFu; best.sx = 0u; best.rank = 0u;
-        float t_max = t_hi;
+    Closest held = {INF, 0xFFFFFFFFu, 0u, 0u};  // the reduction's accumulator
+    Closest local = {INF, 0xFFFFFFFFu, 0u, 0u}; // closest of the group being walked
+    float4 local_b0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), local_b1 = local_b0; // outer box of the primitive taken last
+    bool local_nested = false;
+    uint32_t below = 0xFFFFFFFFu; // ranks still to come
+    uint32_t group = 0xFFFFFFFFu;
+    float closest_t = t_hi, bound = t_hi;
+    for (;;) {
+        // closest_t as the groups after this one will get it
+        const float handed_on = (group != 0xFFFFFFFFu && group != 0u && !(held.t <= local.t)) ? local.t : closest_t;
+        const float widest = fmaxf(bound, handed_on);
+        Closest next = {INF, 0xFFFFFFFFu, 0u, 0u};
+        float4 next_b0 = local_b0, next_b1 = local_b1;
+        bool next_nested = false;
         o = wo; d = wd;
         BoxRay R;
         box_frame(S, o, d, R);
@@ -771,14 +847,21 @@ __device__ __forceinline__ Closest surface_again(WalkScene A, f3 o, f3 d, float 
                 continue;
             }
             uint32_t leaf;
-            node_step(S, R, t_min, t_max, node, leaf);
+            node_step(S, R, t_min, widest, node, leaf);
             if (leaf == 0u) continue;
             const uint32_t prim = (leaf & RT_LEAF_PRIM_MASK) - 1u;
             uint4 hd;
             Geom G;
             load_prim(S, prim, hd, G);
+            const float4 b0 = S.prim_box[4u * prim], b1 = S.prim_box[4u * prim + 1u];
+            const uint32_t rank = (leaf & RT_LEAF_INSTANCE) ? hd.z : hd.z + inst_rank; // (a nested tree lies in one group)
+            const bool in_group = group_of(S, rank) == group;
+            const float lim = in_group ? bound : handed_on;
+            // the nested tree the reference is inside of once it has taken a hit there: its outer box was passed before
+            const bool same_tree = in_group && local_nested && b0.x == local_b0.x && b0.y == local_b0.y && b0.z == local_b0.z &&
+                                   b0.w == local_b0.w && b1.x == local_b1.x && b1.y == local_b1.y;
             if (leaf & RT_LEAF_INSTANCE) { // Transform{BVHTree}: src/transform.jl:104-116 around src/BVH.jl:22-53
-                if (!ref_reaches<true>(S, prim, 0u, o, d, t_min, t_hi)) continue;
+                if (!same_tree && !ref_reaches<true>(S, prim, b0, b1, 0u, o, d, t_min, lim)) continue;
                 const uint32_t field = hd.x >> 8;
                 ret = node; ret_end = end;
                 inst_rank = hd.z;
@@ -791,17 +874,163 @@ __device__ __forceinline__ Closest surface_again(WalkScene A, f3 o, f3 d, float 
                 box_frame(S, o, d, R);
                 node = __float_as_uint(G.g[0]) + layout_base(S, d) + set;
                 end = node + __float_as_uint(G.g[1]);
-            } else {
-                surface_leaf<true>((const float*)(S.prim_inv + 3u * prim), prim, hd, G, o, d, time, t_min, t_max, inst_rank, inst_xf,
-                                   best, floor_t, floor_rank);
+                continue;
             }
+            if (rank >= below || (next.prim != 0xFFFFFFFFu && rank <= next.rank)) continue;
+            const uint32_t kind = hd.x & 15u;
+            const uint32_t field = kind == DP_TRIANGLE ? 0u : hd.x >> 8;
+            float unused;
+            if (!ref_reaches<true>(S, prim, b0, b1, field ? field : inst_xf, wo, wd, t_min, lim, unused, same_tree)) continue;
+            uint32_t side = 0, xf = inst_xf;
+            const float t = surface_t((const float*)(S.prim_inv + 3u * prim), kind, field, G.g, o, d, time, t_min, lim, side, xf);
+            if (!(t < INF) || (in_group && !(t < local.t))) continue; // strict: an equal distance keeps the earlier hit
+            next.t = t; next.prim = prim; next.sx = side | (xf << 3) | ((hd.x & DP_TYPE_MASK) << 24); next.rank = rank;
+            next_b0 = b0; next_b1 = b1;
+            next_nested = (__float_as_uint(b1.z) & RT_BOX_INNER) != 0u;
         }
-    } while (best.t != INF && !ref_reaches<false>(S, best.prim, (best.sx >> 3) & 0x3FFFFFFu, wo, wd, t_min, t_hi));
+        const uint32_t g = next.prim != 0xFFFFFFFFu ? group_of(S, next.rank) : 0xFFFFFFFFu;
+        if (g != group) { // the group is done: its closest hit goes into the reduction
+            if (group == 0u) held = local;
+            else if (group != 0xFFFFFFFFu && !(held.t <= local.t)) { held = local; closest_t = local.t; }
+            group = g;
+            local.t = INF; local.prim = 0xFFFFFFFFu;
+        }
+        if (next.prim == 0xFFFFFFFFu) break;
+        local = next; local_b0 = next_b0; local_b1 = next_b1; local_nested = next_nested;
+        bound = local.t;
+        below = local.rank;
+    }
+    return held;
+}
+// The closest hit behind (floor_t, floor_rank) in the order (distance, then higher rank first), no further than t_bound;
+// none: t = INF.  One walk of the device tree with the usual shrinking bound.
+__device__ __forceinline__ Closest next_hit_after(const DevScene& S, f3 wo, f3 wd, float time, float t_min, float t_bound,
+                                                  float floor_t, uint32_t floor_rank) {
+    Closest best = {INF, 0xFFFFFFFFu, 0u, 0u};
+    float t_max = t_bound;
+    f3 o = wo, d = wd;
+    BoxRay R;
+    box_frame(S, o, d, R);
+    const uint32_t set = node_set(S, wo);
+    uint32_t node = S.surface_root + layout_base(S, d) + set, end = node + S.surface_size;
+    uint32_t ret = RT_NODE_NONE, ret_end = 0u, inst_rank = 0u, inst_xf = 0u;
+    for (;;) {
+        if (node == end) {
+            if (ret == RT_NODE_NONE) break;
+            o = wo; d = wd; // back out of the nested tree
+            box_frame(S, o, d, R);
+            node = ret; end = ret_end;
+            ret = RT_NODE_NONE;
+            inst_rank = 0u; inst_xf = 0u;
+            continue;
+        }
+        uint32_t leaf;
+        node_step(S, R, t_min, t_max, node, leaf);
+        if (leaf == 0u) continue;
+        const uint32_t prim = (leaf & RT_LEAF_PRIM_MASK) - 1u;
+        uint4 hd;
+        Geom G;
+        load_prim(S, prim, hd, G);
+        if (leaf & RT_LEAF_INSTANCE) { // Transform{BVHTree}: src/transform.jl:104-116 around src/BVH.jl:22-53
+            if (!ref_reaches<true>(S, prim, 0u, o, d, t_min, INF)) continue; // hits in front of that box count too
+            const uint32_t field = hd.x >> 8;
+            ret = node; ret_end = end;
+            inst_rank = hd.z;
+            inst_xf = field;
+            if (field) {
+                const float* T = S.xforms + 24u * (field - 1u) + 12;
+                f3 no = apply_point(T, o), nd = apply_vec(T, d);
+                o = no; d = nd;
+            }
+            box_frame(S, o, d, R);
+            node = __float_as_uint(G.g[0]) + layout_base(S, d) + set;
+            end = node + __float_as_uint(G.g[1]);
+        } else {
+            surface_leaf<true>((const float*)(S.prim_inv + 3u * prim), prim, hd, G, o, d, time, t_min, t_max, inst_rank, inst_xf,
+                               best, floor_t, floor_rank);
+        }
+    }
     return best;
+}
+
+// For a ray whose closest surface hit does not stand (hit_stands; about one ray in a hundred thousand): the hit the
+// reference ends up with.  Only the hits at the front can matter.  Let N be the closest hit that stands on its own
+// (reached, not in front of its box) and T the largest of N's distance and the box-entry distances of the hits in front
+// of their boxes found up to T.  A hit beyond T is never the last one taken (N is closer), and the bound it leaves
+// behind, being beyond T, neither culls a box nor turns down a hit among those up to T.  So the hits up to T are listed
+// (closest first, one cheap walk each), and the reference's sequence (see reference_sequence) is played over that
+// short list; if the list overflows, over the whole scene.
+#define SETTLE_LIST 6
+// first: the closest of all the hits the primitives report (what the walk of the device tree found).
+__device__ __forceinline__ Closest surface_again(WalkScene A, f3 o, f3 d, float time, float t_min, float t_hi, Closest first) {
+    DevScene S = {};
+    S.nodes = A.nodes; S.prims = A.prims; S.prim_box = A.prim_box; S.prim_inv = A.prim_inv; S.xforms = A.xforms;
+    S.n_nodes = A.n_nodes; S.surface_root = A.surface_root; S.surface_size = A.surface_size;
+    S.node_scale = A.node_scale; S.inv_node_scale = A.inv_node_scale;
+    S.far_set = A.far_set; S.centre[0] = A.cx; S.centre[1] = A.cy; S.centre[2] = A.cz; S.radius2 = A.radius2;
+    S.bucket_base = A.bucket_base; S.n_buckets = A.n_buckets;
+    Closest list[SETTLE_LIST];
+    int n = 0;
+    bool solid = false;
+    float T = t_hi, front = t_min; // front: largest box-entry distance among the hits in front of their boxes
+    float floor_t = -INF;
+    uint32_t floor_rank = 0u;
+    for (bool start = true;; start = false) {
+        if (!start && solid && !(T > floor_t)) break; // nothing in front reaches beyond the hit that stands: the list is complete
+        const Closest c = start ? first : next_hit_after(S, o, d, time, t_min, T, floor_t, floor_rank);
+        if (c.t == INF) break;
+        floor_t = c.t; floor_rank = c.rank;
+        const float4* b = S.prim_box + 4u * c.prim;
+        float near_up;
+        if (!ref_reaches<false>(S, c.prim, b[0], b[1], (c.sx >> 3) & 0x3FFFFFFu, o, d, t_min, t_hi, near_up)) continue;
+        const bool in_front = (S.prims[3u * c.prim].x & 15u) <= DP_MOVING_SPHERE && c.t < near_up;
+        if (n == SETTLE_LIST) return reference_sequence(S, o, d, time, t_min, t_hi);
+        list[n++] = c;
+        if (in_front) front = fmaxf(front, near_up);
+        if (!solid && !in_front) { solid = true; T = fminf(t_hi, fmaxf(c.t, front)); }
+        else if (solid) T = fminf(t_hi, fmaxf(T, front));
+    }
+    // The reference's sequence over the list, highest rank first.  Inside one type group (one tree) the bound shrinks
+    // with every hit taken (src/BVH.jl:36-47).  Between the groups, hit(::SceneManager) (src/scene_manager.jl:40-52)
+    // hands on `closest_t`, which its reduction only sets when a later group's hit replaces the one held: the first
+    // group's own hit never becomes a bound, and a group that loses leaves it as it was.
+    Closest held = {INF, 0xFFFFFFFFu, 0u, 0u};  // the reduction's accumulator
+    Closest local = {INF, 0xFFFFFFFFu, 0u, 0u}; // closest of the group being walked
+    float closest_t = t_hi, bound = t_hi;
+    uint32_t group = 0xFFFFFFFFu, below = 0xFFFFFFFFu;
+    float4 local_b0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), local_b1 = local_b0;
+    bool local_nested = false;
+    for (int round = 0; round <= n; ++round) {
+        int pick = -1;
+        for (int k = 0; k < n && round < n; ++k)
+            if (list[k].rank < below && (pick < 0 || list[k].rank > list[pick].rank)) pick = k;
+        const uint32_t g = pick >= 0 ? group_of(S, list[pick].rank) : 0xFFFFFFFFu;
+        if (g != group) { // the group is done: its closest hit goes into the reduction
+            if (group == 0u) held = local;
+            else if (group != 0xFFFFFFFFu && !(held.t <= local.t)) { held = local; closest_t = local.t; }
+            group = g;
+            local.t = INF; local.prim = 0xFFFFFFFFu;
+            local_nested = false;
+            bound = closest_t;
+        }
+        if (pick < 0) break;
+        const Closest c = list[pick];
+        below = c.rank;
+        const float4 b0 = S.prim_box[4u * c.prim], b1 = S.prim_box[4u * c.prim + 1u];
+        const bool same_tree = local_nested && b0.x == local_b0.x && b0.y == local_b0.y && b0.z == local_b0.z && b0.w == local_b0.w &&
+                               b1.x == local_b1.x && b1.y == local_b1.y;
+        float unused;
+        if (!ref_reaches<false>(S, c.prim, b0, b1, (c.sx >> 3) & 0x3FFFFFFu, o, d, t_min, bound, unused, same_tree)) continue;
+        if (!(c.t <= bound) || !(c.t < local.t)) continue; // an equal distance keeps the earlier hit
+        local = c; local_b0 = b0; local_b1 = b1;
+        local_nested = (__float_as_uint(b1.z) & RT_BOX_INNER) != 0u;
+        bound = c.t;
+    }
+    return held;
 }
 // `best` as the reference would have it: unchanged if the reference reaches that hit (or there is none)
 __device__ __forceinline__ void settle_surface(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_hi, Closest& best) {
-    if (best.t != INF && !ref_reaches<false>(S, best.prim, (best.sx >> 3) & 0x3FFFFFFu, o, d, t_min, t_hi))
+    if (best.t != INF && !hit_stands(S, best.prim, (best.sx >> 3) & 0x3FFFFFFu, o, d, t_min, t_hi, best.t))
         best = surface_again(walk_scene(S), o, d, time, t_min, t_hi, best);
 }
 
@@ -1409,9 +1638,9 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
     }
 }
 
-// The slots that rt_shade_kernel put on hold: the closest surface rt_extend_kernel found for their ray is one the
-// reference does not reach (ref_reaches).  Each ray is walked again for the closest hit behind that one which the
-// reference does reach (surface_again); the hit record is marked settled, and the next rt_shade_kernel shades it.
+// The slots that rt_shade_kernel put on hold: the closest surface rt_extend_kernel found for their ray does not stand
+// (hit_stands: the reference does not reach it, or it lies in front of its own box).  surface_again finds the hit the
+// reference ends up with; the hit record is marked settled, and the next rt_shade_kernel shades it.
 // Runs once per batch of bounces: a slot may wait a few launches, which changes nothing for its path.
 // sync[RT_REDO_COUNT]: number of entries in pool.redo, reset by the last workgroup to finish (sync[RT_REDO_COUNT + 1]
 // counts the finished ones).
@@ -1465,7 +1694,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
             ray0[t] = q0;
             const f3 o = mk3(q0.x, q0.y, q0.z), d = mk3(q1.x, q1.y, q1.z);
             // rt_extend_kernel found the closest surface of the device tree.  Here, with every lane holding a ray, that
-            // hit is held against the boxes of the reference's trees (ref_reaches).  In the rare case that it does not
+            // hit is held against the boxes of the reference's trees (hit_stands).  In the rare case that it does not
             // stand the slot is put on hold: rt_redo_kernel finds the hit that does, and the slot is shaded a few
             // launches later.
             Closest best;
@@ -1474,7 +1703,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
             const bool held = (__float_as_uint(q1.w) & DEPTH_HOLD) != 0u;
             if (held && !(__float_as_uint(q4.w) & RANK_SETTLED)) {
                 q4.w = __uint_as_float(HIT_WAIT); // still waiting for rt_redo_kernel
-            } else if (!held && best.t != INF && !ref_reaches<false>(S, best.prim, (best.sx >> 3) & 0x3FFFFFFu, o, d, 0.001f, INF)) {
+            } else if (!held && best.t != INF && !hit_stands(S, best.prim, (best.sx >> 3) & 0x3FFFFFFu, o, d, 0.001f, INF, best.t)) {
                 // plane 3 keeps {t, prim, sx, rank} of the hit that does not stand: where the redo starts from
                 reinterpret_cast<uint32_t*>(&QP(pool, 1, base + t))[3] = __float_as_uint(q1.w) | DEPTH_HOLD;
                 pool.redo[atomicAdd(sync + RT_REDO_COUNT, 1u)] = base + t;

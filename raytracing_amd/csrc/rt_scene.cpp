@@ -460,6 +460,7 @@ struct Builder {
         }
         std::vector<uint32_t> base((size_t)D.n_buckets, 0);
         for (int b = D.n_buckets - 2; b >= 0; --b) base[(size_t)b] = base[(size_t)b + 1] + totals[(size_t)b + 1];
+        H.bucket_base = base;
         // tree 0: every surface; "tree" 1: the constant media, which the kernels take as a list after the surfaces (they are
         // few) -- no nodes are built for them; trees 2..: nested trees kept as instances.  Collected here as leaves with the
         // reference's boxes; rt_build_nodes makes the device trees.
@@ -509,7 +510,7 @@ struct Builder {
         for (const HostItem& it : H.items)
             for (int k = 0; k < 6; ++k)
                 if (std::isfinite(it.ref[k])) H.scene_reach = std::max(H.scene_reach, (double)std::fabs(it.ref[k]));
-        rt_build_nodes(&H, 2.0 * H.scene_reach);
+        rt_build_nodes(&H, 1.05 * H.scene_reach); // rays scattered inside the scene start inside its boxes
         return true;
     }
 };
@@ -638,9 +639,49 @@ void rt_build_nodes(HostScene* out, double reach) {
         }
     }
     const bool two_sets = n_tight != 0 && radius > 0.0 && std::isfinite(radius);
-    if (n_tight != 0 && !two_sets) tight = loose; // no ball in which every tight box is valid: one set of loose boxes
     H.n_sets = two_sets ? 2u : 1u;
     H.radius = two_sets ? (float)(radius * 0.999) : INFINITY;
+    // The walk drops a box that begins behind the closest hit so far, so a box must hold every point at which its
+    // primitive can report a hit.  The sphere test (src/sphere.jl:45-65) reports points with
+    // |p - c|^2 <= r^2 + 1.4e-6 |o - c|^2 (the rounding of its discriminant, see tight_box): sphere leaves, and the
+    // leaves of nested trees (which may hold spheres), grow by sqrt(r^2 + 1.4e-6 D^2) - r, D the largest distance a ray
+    // of the set can have come: sqrt(3) reach + |c| for set 1, the ball's radius + |c - centre| for set 0 (whose
+    // tightened spheres already carry their own allowance inside the ball).
+    for (size_t k = 0; k < n; ++k) {
+        const uint32_t prim = (H.items[k].leaf & RT_LEAF_PRIM_MASK) - 1u;
+        const uint4 h = H.prims[3 * (size_t)prim], g1 = H.prims[3 * (size_t)prim + 1], g2 = H.prims[3 * (size_t)prim + 2];
+        const uint32_t kind = h.x & 15u;
+        if (kind != DP_SPHERE && kind != DP_MOVING_SPHERE && kind != DP_INSTANCE) continue;
+        double r = 0.0; // nested trees: the largest allowance
+        if (kind == DP_SPHERE) r = std::fabs((double)bitsf(g1.z));
+        if (kind == DP_MOVING_SPHERE) r = std::fabs((double)bitsf(g2.w));
+        if (kind != DP_INSTANCE && (h.x >> 8) != 0u) { // inside a Transform: the radius as the world sees it, at least
+            const float* M = &H.xforms[24 * (size_t)((h.x >> 8) - 1u)];
+            double shrink = INFINITY;
+            for (int i = 0; i < 3; ++i) shrink = std::min(shrink, std::sqrt((double)M[i] * M[i] + (double)M[3 + i] * M[3 + i] + (double)M[6 + i] * M[6 + i]));
+            r *= std::min(1.0, shrink);
+        }
+        if (!std::isfinite(r)) r = 0.0;
+        auto grow = [&](float* b, double D) {
+            const double e = std::sqrt(r * r + 1.4e-6 * D * D) - r;
+            for (int i = 0; i < 3; ++i) {
+                if (!(b[i] <= b[3 + i])) return; // NaN: left alone
+                b[i] = std::nextafter((float)((double)b[i] - e), -INFINITY);
+                b[3 + i] = std::nextafter((float)((double)b[3 + i] + e), INFINITY);
+            }
+        };
+        double far_c = 0.0, off_c = 0.0; // farthest corner of the box from the origin / from the ball's centre
+        for (int i = 0; i < 3; ++i) {
+            const double a0 = std::max(std::fabs((double)loose[k].b[i]), std::fabs((double)loose[k].b[3 + i]));
+            const double a1 = std::max(std::fabs((double)loose[k].b[i] - H.centre[i]), std::fabs((double)loose[k].b[3 + i] - H.centre[i]));
+            if (std::isfinite(a0)) far_c += a0 * a0;
+            if (std::isfinite(a1)) off_c += a1 * a1;
+        }
+        const bool tightened = valid[k] != INFINITY;
+        grow(loose[k].b, std::sqrt(3.0) * reach + std::sqrt(far_c) + (H.items[k].tree >= 2u ? H.scene_reach : 0.0)); // nested: box in the tree's own frame
+        if (two_sets && !tightened) grow(tight[k].b, (double)H.radius + std::sqrt(off_c));
+    }
+    if (!two_sets) tight = loose; // no ball in which every tight box is valid: one set of loose boxes
     const uint32_t n_trees = (uint32_t)H.tree_first.size();
     const uint32_t per_layout = H.nodes_per_layout;
     H.nodes.clear();

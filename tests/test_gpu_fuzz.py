@@ -1,13 +1,13 @@
 """Random scenes against the oracle: every kind of object, wrapper, material and texture the path supports, thrown
 together with a seeded generator -- closest hits of fixed rays and whole images must be identical bit for bit.
 
-One known exception, kept visible here: a camera 30 or 400 scene sizes away.  There the reference's sphere test
-(src/sphere.jl:45-65) has lost its digits -- the discriminant's rounding noise, 7e-7 |o - c|^2 |d|^2, exceeds r^2 |d|^2 --
-and reports hits up to 1e-3 |o - c| in front of the sphere's own leaf box.  Which of two such hits the reference
-keeps then depends on the order in which its trees meet them (the later one's box is culled by the earlier hit's
-distance, src/BVH.jl:22-53 with src/bounding_box.jl:20-67), and the device tree culls by the same kind of bound in
-its own order.  About one such ray in 70 000 comes out differently (3 % of these scenes differ in one ray or
-pixel); the test bounds that instead of hiding the scenes."""
+One known exception, kept visible here: a camera 30 or 400 scene sizes away from a scene with constant media.  From
+that far the reference's sphere test (src/sphere.jl:45-65) has lost its digits -- the discriminant's rounding noise,
+1.4e-6 |o - c|^2 |d|^2, exceeds r^2 |d|^2 -- and reports hits in front of the sphere's own leaf box.  Which of two such
+hits the reference keeps depends on the order in which its trees meet them and on the bound each tree is handed
+(src/BVH.jl:22-53, src/scene_manager.jl:40-52).  The library plays that sequence for surfaces (3000 scenes without
+media: identical); with the boundary of a medium among such hits about one path in 500 000 still differs (16 of
+1000 such scenes, one pixel each), and the test bounds that instead of hiding the scenes."""
 import math
 import os
 
@@ -77,6 +77,8 @@ def random_scene(seed):
     world = []
     for _ in range(int(g.integers(4, 30))):
         k = g.integers(0, 12)
+        if os.environ.get("RT_AMD_FUZZ_NO_MEDIA") and k in (9, 11):
+            k = 0
         if k < 3:
             world.append(sphere())
         elif k == 3:
@@ -109,7 +111,8 @@ def random_scene(seed):
 @pytest.mark.parametrize("seed", range(1, 1 + int(os.environ.get("RT_AMD_FUZZ_SCENES", "24"))))
 def test_random_scene(seed):
     world, cam, bg = random_scene(seed)
-    far_camera = seed % 3 == 1      # see the module comment
+    # see the module comment
+    far_camera = seed % 3 == 1 and any(isinstance(x, rt.ConstantMedium) for x in world) and not os.environ.get("RT_AMD_FUZZ_STRICT")
     W, H = 40, 32
     pat = rt.Halton_sequence32(6)
     ref = O.OracleScene(world)
