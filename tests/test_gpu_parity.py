@@ -348,6 +348,23 @@ def test_scene_from_a_file_renders_the_same_picture(name, scenes, tmp_path):
     np.testing.assert_array_equal(bits(got), bits(want))
 
 
+def test_a_hit_in_front_of_its_box():
+    """The two far spheres of the oracle's known-answer test: whether the smaller root wins depends on the type groups
+    the reference sorts them into; the device gives the reference's answer in each case (hit_stands, surface_again)"""
+    from test_oracle_kat import _two_far_spheres
+    ray, worlds = _two_far_spheres()
+    for name, world in worlds.items():
+        want = O.OracleScene(world).trace_rays(ray)
+        dev = rt.DeviceScene(world)
+        try:
+            got = dev.trace_rays(ray)
+        finally:
+            dev.close()
+        assert got["prim_id"][0] == want["prim_id"][0], name
+        np.testing.assert_array_equal(bits(got["t"]), bits(want["t"]))
+        np.testing.assert_array_equal(bits(got["normal"]), bits(want["normal"]))
+
+
 def test_device_output_stage_matches_host_quantisation(scenes):
     """rt_finalize_rgb8 (clamp01 + N0f8 on the device) == rt_finalize followed by the host quantisation"""
     import torch

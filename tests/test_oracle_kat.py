@@ -336,3 +336,36 @@ def test_render_layout_and_gamma():
     assert img.shape == (4, 6, 3)
     np.testing.assert_array_equal(img[0], np.full((6, 3), 2.0, F))   # top row sees the light, sqrt(4) = 2 (not clamped)
     np.testing.assert_array_equal(img[3], np.zeros((6, 3), F))
+
+
+def _two_far_spheres():
+    """Two spheres seen from 9000 away, where the sphere test (src/sphere.jl:45-65) has lost its digits: B's root
+    (0.8658094) lies in front of B's own box (entered at 0.8659409), A's root (0.8658121) in between."""
+    ray = np.array([[-103.47892761230469, 8866.81640625, -2951.947509765625,
+                     124.83503723144531, -10233.1455078125, 3403.513916015625, 0.1916230320930481]], np.float32)
+    a = lambda tex: rt.Sphere(rt.Vec3(4.6211205, 6.9095955, -4.923138), 0.9200988, rt.Material(rt.Lambertian, tex))
+    b = lambda tex: rt.Sphere(rt.Vec3(3.8248086, 3.4844747, -5.6529064), 2.0317829, rt.Material(rt.Lambertian, tex))
+    solid = lambda: rt.SolidColor(rt.Vec3(0.5))
+    check = lambda: rt.CheckerTexture(rt.Vec3(0.1), rt.Vec3(0.9))      # another texture type: another type group
+    worlds = {"A|B": [a(solid()), b(check())], "B|A": [b(check()), a(solid())],
+              "A,B": [a(solid()), b(solid())], "B,A": [b(solid()), a(solid())]}
+    return ray, worlds
+
+
+def test_a_hit_in_front_of_its_box_and_the_bound_between_type_groups():
+    """In one tree A is met first and its distance culls B's box although B's root is the smaller one
+    (src/BVH.jl:36-47 with src/bounding_box.jl:20-67).  In two type groups B is tested with the ray's own t_max, whichever
+    comes first: hit(::SceneManager) only hands on `closest_t` when a later group's hit replaces the one held, so the first
+    group's hit never becomes a bound (src/scene_manager.jl:40-52), and B's smaller root wins the reduction."""
+    ray, worlds = _two_far_spheres()
+    t_a, t_b = np.float32(0.8658121228218079), np.float32(0.865809440612793)
+    want = {"A|B": (1, t_b), "B|A": (0, t_b), "A,B": (0, t_a), "B,A": (1, t_a)}
+    for name, world in worlds.items():
+        hit = O.OracleScene(world).trace_rays(ray)
+        assert (int(hit["prim_id"][0]), hit["t"][0]) == want[name], name
+    # B's box for this ray, as the reference computes it
+    o, d = ray[0, :3], ray[0, 3:6]
+    c, r = np.array([3.8248086, 3.4844747, -5.6529064], np.float32), np.float32(2.0317829)
+    t0, t1 = ((c - r) - o) / d, ((c + r) - o) / d
+    entry = np.minimum(t0, t1).max()
+    assert t_b < t_a < entry < np.maximum(t0, t1).min()
