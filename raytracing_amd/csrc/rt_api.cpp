@@ -56,6 +56,8 @@ struct rtScene {
     hipStream_t last_stream = nullptr;
     uint64_t last_paths = 0;
     hipEvent_t* events = nullptr;                      // 3 per bounce of a batch, RT_FLAG_TIMING only
+    hipStream_t side = nullptr;                        // rt_redo_kernel runs here, beside the first extend kernel of a batch
+    hipEvent_t fork = nullptr, join = nullptr;
     double last_extend_s = 0.0, last_shade_s = 0.0;
     uint64_t last_extend_launches = 0, last_shade_launches = 0;
 };
@@ -262,6 +264,7 @@ int rt_scene_destroy(rtScene* s) {
     if (s->d_radiance) (void)hipFree(s->d_radiance);
     if (s->d_pool) (void)hipFree(s->d_pool);
     if (s->d_redo) (void)hipFree(s->d_redo);
+    if (s->side) { (void)hipStreamDestroy(s->side); (void)hipEventDestroy(s->fork); (void)hipEventDestroy(s->join); }
     if (s->d_pool2) (void)hipFree(s->d_pool2);
     if (s->d_counts) (void)hipFree(s->d_counts);
     if (s->d_sync) (void)hipFree(s->d_sync);
@@ -321,6 +324,11 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
     if (st != RT_OK) return st;
     pool.q = s->d_pool;
     pool.redo = s->d_redo;
+    if (!s->side && !std::getenv("RT_AMD_NO_REDO_OVERLAP")) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->join, hipEventDisableTiming));
+    }
     HIP_TRY(hipMemcpyAsync(s->d_pattern, pattern, (size_t)2 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, stream));
     bool count = (flags & RT_FLAG_COUNTERS) != 0;
     if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), stream));
@@ -363,10 +371,25 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
         // bounces in batches and stops after the first batch that ends with none.
         for (uint64_t bounce = 0;; bounce += batch) {
             HIP_TRY(hipMemsetAsync(s->d_sync + 2, 0, BOUNCE_BATCH * sizeof(uint32_t), stream));
-            if (bounce != 0) rt_launch_redo(&s->dev, &pool, s->d_sync, stream);
+            // The slots on hold are settled between two batches.  rt_extend_kernel leaves them alone and rt_redo_kernel
+            // touches nothing else, so the two run side by side (the redo is a few lone lanes walking the tree); the
+            // batch's first shade kernel waits for it.  Before a compaction, which moves the slots, it runs in line.
+            const bool compacting = tail && pool.n_slots > 4096u && !std::getenv("RT_AMD_NO_COMPACT");
+            bool beside = false;
+            if (bounce != 0) {
+                if (!compacting && s->side) {
+                    HIP_TRY(hipEventRecord(s->fork, stream));
+                    HIP_TRY(hipStreamWaitEvent(s->side, s->fork, 0));
+                    rt_launch_redo(&s->dev, &pool, s->d_sync, s->side);
+                    HIP_TRY(hipEventRecord(s->join, s->side));
+                    beside = true;
+                } else {
+                    rt_launch_redo(&s->dev, &pool, s->d_sync, stream);
+                }
+            }
             // No unstarted path left: the slots run dry over the next (up to max_depth) bounces.  The ones that still
             // hold a ray are moved together, so that the launches shrink with them.
-            if (tail && pool.n_slots > 4096u && !std::getenv("RT_AMD_NO_COMPACT")) {
+            if (compacting) {
                 st = ensure(&s->d_pool2, &s->pool2_cap, (size_t)5 * frame_slots);
                 if (st == RT_OK) st = ensure(&s->d_counts, &s->counts_cap, (size_t)frame_slots / 256 + 2);
                 if (st != RT_OK) return st;
@@ -380,7 +403,8 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
             }
             for (uint32_t b = 0; b < batch; ++b)
                 rt_launch_bounce(&s->dev, &cam, s->d_pattern, &P, &pool, extend_blocks, s->d_radiance, s->d_sync,
-                                 s->d_sync + 2u + b, s->d_counters, count, timing ? s->events + 3u * b : nullptr, stream);
+                                 s->d_sync + 2u + b, s->d_counters, count, timing ? s->events + 3u * b : nullptr, stream,
+                                 (b == 0u && beside) ? s->join : nullptr);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(s->h_sync, s->d_sync + 1u + batch, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(s->h_sync + 2, s->d_sync + RT_TAIL_FLAG, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

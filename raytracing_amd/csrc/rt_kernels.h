@@ -54,7 +54,8 @@ void rt_launch_init(const RtCameraDev* cam, const float* d_pattern, const RtRend
 // bounce.
 void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, const float* d_pattern, const RtRenderParams* P,
                       const PathPool* pool, uint32_t extend_blocks, float4* d_radiance, uint32_t* d_sync, uint32_t* d_active,
-                      unsigned long long* d_counters, bool count, hipEvent_t* timing, hipStream_t stream);
+                      unsigned long long* d_counters, bool count, hipEvent_t* timing, hipStream_t stream,
+                      hipEvent_t before_shade = nullptr); // before_shade: the shade kernel waits for this event (rt_redo_kernel on another stream)
 // settles the slots that the shade kernel put on hold since the last call; to be enqueued between batches of bounces
 void rt_launch_redo(const DevScene* S, const PathPool* pool, uint32_t* d_sync, hipStream_t stream);
 // The slots of `from` that hold a ray, moved to the front of the pool `to` (same order), which has

@@ -2017,7 +2017,7 @@ extern "C" void rt_launch_init(const RtCameraDev* cam, const float* d_pattern, c
 extern "C" void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, const float* d_pattern, const RtRenderParams* P,
                                  const PathPool* pool, uint32_t extend_blocks, float4* d_radiance, uint32_t* d_sync,
                                  uint32_t* d_active, unsigned long long* d_counters, bool count, hipEvent_t* timing,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, hipEvent_t before_shade) {
     // timing (optional): three events, before extend / between / after shade
     uint32_t shade_blocks = (pool->n_slots + SHADE_BLOCK - 1u) / SHADE_BLOCK;
     if (timing) (void)hipEventRecord(timing[0], stream);
@@ -2026,6 +2026,7 @@ extern "C" void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, cons
     else if (count) hipLaunchKernelGGL((rt_extend_kernel<true, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
     else if (nested) hipLaunchKernelGGL((rt_extend_kernel<false, true>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
     else hipLaunchKernelGGL((rt_extend_kernel<false, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    if (before_shade) (void)hipStreamWaitEvent(stream, before_shade, 0);
     if (timing) (void)hipEventRecord(timing[1], stream);
     if (S->textured) hipLaunchKernelGGL(rt_shade_kernel<true>, dim3(shade_blocks), dim3(SHADE_BLOCK), 0, stream, *S, *cam, d_pattern, *P, *pool,
                                         d_radiance, d_sync, d_active);
