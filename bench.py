@@ -127,7 +127,7 @@ def main():
                        "paths_per_frame": paths_per_frame},
         }
         roofline, cpu = None, None
-        if not args.no_cpu and world_size == 1:
+        if not args.no_cpu:
             # bounded CPU sample: the checker (a C++ port of the reference's CPU path, threads over columns) renders
             # the same scene at full resolution with a few pattern columns; it also counts the events of the
             # reference algorithm, which define the algorithmic flops/bytes per path used for the roofline.
@@ -135,22 +135,26 @@ def main():
             import oracle_ffi as O
             cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
             ref = O.OracleScene(world)
-            cpu_pat = rt.Halton_sequence32(args.cpu_spp)
+            # (with more than one GPU the CPU baseline is not reported; a few columns then give the event counts)
+            cpu_cols = args.cpu_spp if world_size == 1 else min(4, args.cpu_spp)
+            cpu_pat = rt.Halton_sequence32(cpu_cols)
             _, st = ref.render(cam, cpu_pat, bg, W, H, threads=cores, stats=True)
-            cpu = {"value": st.paths / st.seconds / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
-                   "sample": "%s %dx%d, %d of %d pattern columns (%.1f s)" % (args.scene, W, H, args.cpu_spp, n, st.seconds)}
+            if world_size == 1:
+                cpu = {"value": st.paths / st.seconds / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
+                       "sample": "%s %dx%d, %d of %d pattern columns (%.1f s)" % (args.scene, W, H, cpu_cols, n, st.seconds)}
             flops_pp, bytes_pp, events = algorithmic_work(st)
             # Dominant kernel = rt_extend_kernel (BVH traversal + intersection).  Its launches of one extra frame are
             # bracketed with HIP events on the launch stream (RT_FLAG_TIMING); algorithmic work per launch = the
             # traversal/intersection share of the per-path work x the paths of a frame / launches.
             from raytracing_amd import _ffi
-            scene.accumulate(cam, pattern, bg, W, H, accum.data_ptr(), flags=_ffi.RT_FLAG_TIMING, stream=stream)
+            scene.accumulate(cam, pattern, bg, W, H, accum.data_ptr(), sample_first=rank, sample_stride=world_size,
+                             flags=_ffi.RT_FLAG_TIMING, stream=stream)  # this rank's shard of the columns
             tst = scene.counters()
             trav = sum(events[k] * COST[k][0] for k in ("node", "sphere", "moving_sphere", "rect", "box", "transform", "medium", "triangle"))
             trav_b = sum(events[k] * COST[k][1] for k in ("node", "sphere", "moving_sphere", "rect", "box", "transform", "medium", "triangle"))
             launches = max(1, tst.extend_launches)
             avg_s = tst.extend_seconds / launches
-            paths_per_launch = W * H * n / launches
+            paths_per_launch = W * H * len(range(rank, n, world_size)) / launches
             tflops = trav * paths_per_launch / avg_s / 1e12
             roofline = {"bound": "valu", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                         "frac": tflops / PEAK_FP32_TFLOPS, "traffic": None,
@@ -175,6 +179,7 @@ def main():
         print(json.dumps(line), flush=True)
     scene.close()
     if world_size > 1:
+        dist.barrier()  # rank 0 measured one more frame for the roofline
         dist.destroy_process_group()
 
 
