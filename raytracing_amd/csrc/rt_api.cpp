@@ -425,6 +425,17 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
             if (bounce > ((uint64_t)P.n_paths / pool.n_slots + 2ull) * 64ull + 4096ull)
                 return rt_fail(RT_EHIP, "rt_render_accumulate: bounce loop did not terminate");
         }
+        if (P.n_paths > frame_slots) {
+            // every path of the batch must have been handed to a slot: the counters are read back and held against
+            // their limits (a path left behind would leave a stale entry in the radiance buffer, silently)
+            HIP_TRY(hipMemcpy2DAsync(s->h_sync + 8, sizeof(uint32_t), s->d_sync + RT_DISP_BASE, RT_DISP_STRIDE * sizeof(uint32_t),
+                                     sizeof(uint32_t), P.n_disp, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            for (uint32_t c = 0; c < P.n_disp; ++c)
+                if (s->h_sync[8u + c] < rt_dispenser_limit(P.n_paths, P.n_disp, c))
+                    return rt_fail(RT_EHIP, "rt_render_accumulate: internal: path dispenser %u stopped at %u of %u", c,
+                                   s->h_sync[8u + c], rt_dispenser_limit(P.n_paths, P.n_disp, c));
+        }
         rt_launch_sum(&P, s->d_radiance, d_accum, k0 == 0u ? 1 : 0, stream);
         HIP_TRY(hipGetLastError());
     }

@@ -23,6 +23,17 @@ struct RtCameraDev { // same field order as rtCamera (src/camera.jl:3-14)
 #define RT_LIVE_SLOTS (RT_REDO_COUNT + 3u) // written by rt_launch_compact: slots that hold a ray
 #define RT_SYNC_WORDS (RT_REDO_COUNT + RT_DISP_STRIDE)
 
+// Local indices path dispenser c (of n_disp) has to hand out for a batch of n_paths paths: v < limit <=> the path
+// ((v / RT_DISP_UNIT) * n_disp + c) * RT_DISP_UNIT + v % RT_DISP_UNIT is below n_paths.  The units are dealt round-robin,
+// so the dispensers differ by at most one unit, and only the last unit of the batch is ragged.
+__host__ __device__ inline uint32_t rt_dispenser_limit(uint32_t n_paths, uint32_t n_disp, uint32_t c) {
+    const uint32_t n_units = (n_paths + RT_DISP_UNIT - 1u) / RT_DISP_UNIT;
+    if (n_units == 0u) return 0u;
+    uint32_t lim = (n_units / n_disp + (c < n_units % n_disp ? 1u : 0u)) * RT_DISP_UNIT;
+    if (c == (n_units - 1u) % n_disp) lim -= n_units * RT_DISP_UNIT - n_paths;
+    return lim;
+}
+
 struct PathPool { // per-slot path state, five float4 planes of n_slots entries each (see rt_kernels.hip)
     float4* q;
     uint32_t* redo; // n_slots entries: slots on hold, whose ray rt_redo_kernel walks again

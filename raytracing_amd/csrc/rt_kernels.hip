@@ -1395,6 +1395,7 @@ __device__ __forceinline__ int path_key(const RtRenderParams& P, uint32_t kk, ui
 __device__ __forceinline__ uint32_t dispensed_path(const RtRenderParams& P, uint32_t c, uint32_t v) {
     return ((v / DISP_UNIT) * P.n_disp + c) * DISP_UNIT + (v % DISP_UNIT);
 }
+__device__ __forceinline__ uint32_t dispenser_limit(const RtRenderParams& P, uint32_t c) { return rt_dispenser_limit(P.n_paths, P.n_disp, c); }
 
 // camera ray of path p into slot `slot`
 __device__ __forceinline__ void start_path(const RtCameraDev& cam, const float* pattern, const RtRenderParams& P,
@@ -1675,7 +1676,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
     __shared__ uint16_t order[SHADE_BLOCK];
     __shared__ float4 hits[SHADE_BLOCK];  // per slot of the block: {t, prim, side|xform, type} after the media
     __shared__ float4 ray0[SHADE_BLOCK], ray1[SHADE_BLOCK], ray2[SHADE_BLOCK]; // planes 0-2 of the block's slots, for phase 2
-    __shared__ uint32_t block_alive, block_need, block_base, block_disp;
+    __shared__ uint32_t block_alive, block_need, block_filled, block_nseg;
+    __shared__ uint32_t seg_first[RT_DISP_MAX + 1], seg_base[RT_DISP_MAX + 1], seg_disp[RT_DISP_MAX + 1]; // the paths the block's finished slots take
     const uint32_t t = threadIdx.x;
     const uint32_t base = blockIdx.x * SHADE_BLOCK;
     if (t < 8u) { hist[t] = 0u; }
@@ -1792,30 +1794,49 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
         wave_pos = (uint32_t)__shfl((int)wave_pos, 0);
     }
     __syncthreads();
-    if (t == 0u) {
+    if (t < 64u) {
         // The unstarted paths are handed out by P.n_disp counters, each 128 bytes from the next, so that the requests of
-        // the workgroups do not queue up on one address.  A workgroup asks its own counter and, once that one has run
-        // dry, its neighbour's.  A counter is left alone after it passed its limit, so it cannot wrap.
-        block_base = 0xFFFFFFFFu;
-        if (block_need) {
-            for (uint32_t k = 0; k < 2u && block_base == 0xFFFFFFFFu; ++k) {
-                uint32_t c = (blockIdx.x + k) % P.n_disp;
-                uint32_t* ctr = sync + DISP_BASE + c * DISP_STRIDE;
-                if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P.disp_limit) {
-                    uint32_t v = atomicAdd(ctr, block_need);
-                    if (v < P.disp_limit) { block_base = v; block_disp = c; }
+        // the workgroups do not queue up on one address.  A workgroup asks its own counter (one lane, one atomic).  Once
+        // that one cannot serve the whole request the first wave looks at every counter, a lane each, and the request is
+        // served from as many of them as it takes (segments): a slot is left without a ray only when EVERY counter has
+        // run dry, so no path can stay behind however the slots are spread over the workgroups (the end-of-frame
+        // compaction moves them).  A counter is left alone once it has passed its limit, so it cannot wrap.
+        const uint32_t need = block_need;
+        uint32_t filled = 0u, nseg = 0u;
+        if (need) {
+            const uint32_t c = (blockIdx.x + t) % P.n_disp;
+            const uint32_t lim = dispenser_limit(P, c);
+            uint32_t* ctr = sync + DISP_BASE + c * DISP_STRIDE;
+            unsigned long long open = 1ull; // the workgroup's own counter first, unseen
+            for (bool first = true; open != 0ull && filled < need; first = false) {
+                const uint32_t l = (uint32_t)__ffsll((long long)open) - 1u;
+                open &= open - 1ull;
+                uint32_t v = 0xFFFFFFFFu;
+                if (t == l && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lim) v = atomicAdd(ctr, need - filled);
+                v = (uint32_t)__shfl((int)v, (int)l);
+                const uint32_t vl = (uint32_t)__shfl((int)lim, (int)l), vc = (uint32_t)__shfl((int)c, (int)l);
+                if (v < vl) {
+                    const uint32_t got = min(need - filled, vl - v);
+                    if (t == 0u) { seg_first[nseg] = filled; seg_base[nseg] = v; seg_disp[nseg] = vc; }
+                    nseg += 1u;
+                    filled += got;
                 }
+                if (first && filled < need) // the other counters that still have something, by the look of them
+                    open = __ballot(t != 0u && t < P.n_disp && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lim);
             }
-            if (block_base == 0xFFFFFFFFu) sync[RT_TAIL_FLAG] = 1u; // every writer stores the same value
+            if (t == 0u && filled < need) sync[RT_TAIL_FLAG] = 1u; // every counter is dry now; every writer stores the same value
         }
+        if (t == 0u) { block_filled = filled; block_nseg = nseg; }
     }
     __syncthreads();
     if (done) {
         bool started = false;
-        if (block_base != 0xFFFFFFFFu) {
-            uint32_t v = block_base + wave_pos + (uint32_t)__popcll(m_done & ((1ull << (t & 63u)) - 1ull));
-            uint32_t p = dispensed_path(P, block_disp, v);
-            if (p < P.n_paths) {
+        const uint32_t idx = wave_pos + (uint32_t)__popcll(m_done & ((1ull << (t & 63u)) - 1ull));
+        if (idx < block_filled) {
+            uint32_t sg = 0u;
+            while (sg + 1u < block_nseg && seg_first[sg + 1u] <= idx) ++sg;
+            const uint32_t p = dispensed_path(P, seg_disp[sg], seg_base[sg] + (idx - seg_first[sg]));
+            if (p < P.n_paths) { // (always: the counters hand out valid indices only)
                 start_path(cam, pattern, P, pool, slot, p);
                 cont = true;
                 started = true;

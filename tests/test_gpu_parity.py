@@ -139,6 +139,47 @@ def test_edge_cases(scenes, monkeypatch):
     assert st.rays >= st.paths > 0 and st.node_visits > st.rays
 
 
+@pytest.mark.parametrize("width,height", [(1024, 64), (512, 128)])
+def test_uneven_columns_drain_every_path_dispenser(width, height, monkeypatch):
+    """An image whose width is a multiple of 256 maps every path dispenser to a fixed band of columns; here the left
+    half of the picture is the sky (one ray per path) and the right half looks into a deep white cavity (14 rays per
+    path on average), so the dispensers run dry at very different times, with few slots and the end-of-frame compaction
+    at work.  Every path must still be traced: the image is the oracle's bit for bit, and the picture at full size
+    (1024 x 1024) does not depend on the number of slots."""
+    from raytracing_amd.hittables import (Camera, Dielectric, Lambertian, Material, Metal, Sphere, Vec3, xy_rect, xz_rect,
+                                          yz_rect)
+    white = Material(Lambertian, Vec3(0.97, 0.97, 0.97))
+    world = [yz_rect(-100, 100, 0, 400, -200, white), yz_rect(-100, 100, 0, 400, -5, white),
+             xz_rect(-200, -5, 0, 400, -100, white), xz_rect(-200, -5, 0, 400, 100, white),
+             xy_rect(-200, -5, -100, 100, 400, white), Sphere(Vec3(-100, 0, 200), 60, Material(Metal, Vec3(0.9, 0.9, 0.9), 0.0)),
+             Sphere(Vec3(-60, 0, 60), 30, Material(Dielectric, Vec3(1, 1, 1), 0.0, 1.5))]
+    origin = Vec3(0, 0, -260)
+    cam = Camera(origin, origin - Vec3(0, 0, 50), Vec3(0, 1, 0), 60.0, width / height, 0.0, 10.0, 0.0, 1.0)
+    bg = Vec3(0.7, 0.8, 1.0)
+    pat = rt.Halton_sequence32(48)
+    ref, dev = O.OracleScene(world), rt.DeviceScene(world)
+    try:
+        monkeypatch.setenv("RT_AMD_SLOTS", "65536")   # 64 path dispensers, and a pool that shrinks far below 64 workgroups
+        img, st = dev.render(cam, pat, bg, width, height)
+        want = ref.render(cam, pat, bg, width, height)
+        np.testing.assert_array_equal(bits(img), bits(want))
+        assert st.paths == width * height * 48
+        left, right = img[:, :width // 4].mean(), img[:, -width // 4:].mean()
+        assert abs(left - np.sqrt(np.array([0.7, 0.8, 1.0])).mean()) < 1e-3 and right < 0.8  # sky on the left only
+        if width == 1024:
+            cam2 = Camera(origin, origin - Vec3(0, 0, 50), Vec3(0, 1, 0), 60.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+            pat2 = rt.Halton_sequence32(12)
+            a, _ = dev.render(cam2, pat2, bg, 1024, 1024)
+            monkeypatch.setenv("RT_AMD_SLOTS", "16384")
+            b, _ = dev.render(cam2, pat2, bg, 1024, 1024)
+            monkeypatch.delenv("RT_AMD_SLOTS")
+            c, _ = dev.render(cam2, pat2, bg, 1024, 1024)
+            np.testing.assert_array_equal(bits(a), bits(c))
+            np.testing.assert_array_equal(bits(b), bits(c))
+    finally:
+        dev.close()
+
+
 def test_errors_on_device(scenes):
     world, kw, dev, ref = scenes("cornell_box")
     L = ffi.lib()
