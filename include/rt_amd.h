@@ -182,7 +182,7 @@ int rt_render(rtScene* scene, const rtCamera* camera, const float* pattern /* 2 
 /* The two halves of rt_render for spp sharding across GPUs (one process per GPU):
  * rt_render_accumulate replaces the @cuda draw_kernel launch (src/Ray_Tracing.jl:151): it WRITES to the device
  * buffer d_accum (3*H*W floats) the un-normalised sum of trace() over pattern columns sample_first,
- * sample_first + sample_stride, ... < n.  rt_finalize replaces `img ./= N; sqrt` (src/Ray_Tracing.jl:152-153):
+ * sample_first + sample_stride, ... < n (none if sample_first >= n: the buffer is zeroed).  rt_finalize replaces `img ./= N; sqrt` (src/Ray_Tracing.jl:152-153):
  * d_out[i] = sqrt(d_accum[i] * Float32(1/n_total)).  Both enqueue on `stream` (a hipStream_t, NULL = default
  * stream) and return without synchronising.  d_accum and d_out may alias. */
 int rt_render_accumulate(rtScene* scene, const rtCamera* camera, const float* pattern, int n, int sample_first,

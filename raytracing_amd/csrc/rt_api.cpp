@@ -53,9 +53,9 @@ struct rtScene {
     int n_cus = 0;
     float* d_accum = nullptr;   size_t accum_cap = 0;
     unsigned long long* d_counters = nullptr;
-    hipStream_t last_stream = nullptr;
     uint64_t last_paths = 0;
     hipEvent_t* events = nullptr;                      // 3 per bounce of a batch, RT_FLAG_TIMING only
+    uint32_t n_events = 0;                             // ... of which this many have been created
     hipStream_t side = nullptr;                        // rt_redo_kernel runs here, beside the first extend kernel of a batch
     hipEvent_t fork = nullptr, join = nullptr;
     double last_extend_s = 0.0, last_shade_s = 0.0;
@@ -96,7 +96,6 @@ int ensure_reach(rtScene* s, double needed) {
     if (!(needed >= 0.0) || !std::isfinite(needed)) needed = 0.0;
     const double target = 2.0 * std::max(needed, H.scene_reach);
     if (H.reach >= needed && H.reach <= 64.0 * target) return RT_OK;
-    if (s->last_stream) HIP_TRY(hipStreamSynchronize(s->last_stream));
     HIP_TRY(hipDeviceSynchronize());
     rt_build_nodes(&H, target);
     return upload_nodes(s);
@@ -264,13 +263,15 @@ int rt_scene_destroy(rtScene* s) {
     if (s->d_radiance) (void)hipFree(s->d_radiance);
     if (s->d_pool) (void)hipFree(s->d_pool);
     if (s->d_redo) (void)hipFree(s->d_redo);
-    if (s->side) { (void)hipStreamDestroy(s->side); (void)hipEventDestroy(s->fork); (void)hipEventDestroy(s->join); }
+    if (s->side) (void)hipStreamDestroy(s->side);
+    if (s->fork) (void)hipEventDestroy(s->fork);
+    if (s->join) (void)hipEventDestroy(s->join);
     if (s->d_pool2) (void)hipFree(s->d_pool2);
     if (s->d_counts) (void)hipFree(s->d_counts);
     if (s->d_sync) (void)hipFree(s->d_sync);
     if (s->h_sync) (void)hipHostFree(s->h_sync);
     if (s->events) {
-        for (uint32_t i = 0; i < 3u * BOUNCE_BATCH; ++i) (void)hipEventDestroy(s->events[i]);
+        for (uint32_t i = 0; i < s->n_events; ++i) (void)hipEventDestroy(s->events[i]);
         delete[] s->events;
     }
     if (s->d_accum) (void)hipFree(s->d_accum);
@@ -279,78 +280,65 @@ int rt_scene_destroy(rtScene* s) {
     return RT_OK;
 }
 
-int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* pattern, int n, int sample_first,
-                         int sample_stride, const float background[3], int width, int height, int max_depth,
-                         uint64_t seed, uint32_t flags, float* d_accum, void* stream_) {
-    if (!s || !camera || !pattern || !d_accum) return rt_fail(RT_EINVAL, "rt_render_accumulate: null argument");
-    if (n <= 0 || sample_first < 0 || sample_first >= n || sample_stride <= 0)
-        return rt_fail(RT_EINVAL, "rt_render_accumulate: need n > 0, 0 <= sample_first < n, sample_stride > 0");
-    RtRenderParams P;
-    int st = fill_params(background, width, height, max_depth, seed, &P);
-    if (st != RT_OK) return st;
-    hipStream_t stream = (hipStream_t)stream_;
-    HIP_TRY(hipSetDevice(s->device));
-    st = ensure_reach(s, camera_reach(camera));
-    if (st != RT_OK) return st;
-    P.sample_first = sample_first;
-    P.sample_stride = sample_stride;
-    const uint32_t n_shard_samples = (uint32_t)((n - sample_first + sample_stride - 1) / sample_stride);
-    // Slots in flight: enough rays per launch to fill the machine many times over.  Default 4 Mi: the four live planes of
-    // the path pool (64 bytes per slot) then just stay inside the 256 MB Infinity Cache between the kernel that writes them
-    // and the one that reads them; throughput falls by 6 % right above that and does not come back before 10 Mi slots.
-    PathPool pool;
-    uint64_t total_paths = (uint64_t)P.n_pixels * n_shard_samples;
-    // A multiple of 16 Ki, so that the paths the slots start with cover whole rounds of the path dispensers.
+// ---- the frame loop of rt_render_accumulate, over buffers the caller of render_frame provides
+struct Workspace {
+    float* pattern;          // 2 * n floats
+    float4* pool;            // 5 planes of n_slots entries
+    uint32_t* redo;          // n_slots entries
+    float4* radiance;        // cols * n_pixels entries
+    uint32_t* sync;          // SYNC_WORDS words
+    uint32_t n_slots;        // slots of the path pool
+    uint32_t cols;           // pattern columns per batch
+    bool may_allocate;       // end-of-frame compaction (second pool), side stream, timing events: only where allocating is allowed
+};
+
+// n_slots and cols for a frame: slots_wanted slots (a multiple of 16 Ki, so that the paths the slots start with cover
+// whole rounds of the path dispensers; fewer if the frame has fewer paths) and as many pattern columns per batch as
+// radiance_entries float4 entries hold.
+static int plan_frame(const RtRenderParams& P, uint32_t n_shard_samples, uint32_t slots_wanted, uint64_t radiance_entries,
+                      uint32_t* n_slots, uint32_t* cols_out) {
+    const uint64_t total_paths = (uint64_t)P.n_pixels * n_shard_samples;
     const uint32_t slot_quantum = RT_DISP_UNIT * RT_DISP_MAX;
-    pool.n_slots = (uint32_t)env_int("RT_AMD_SLOTS", 4 * 1024 * 1024) / slot_quantum * slot_quantum;
-    if (pool.n_slots < slot_quantum) pool.n_slots = slot_quantum;
-    if ((uint64_t)pool.n_slots > total_paths) pool.n_slots = (uint32_t)((total_paths + 1023ull) / 1024ull * 1024ull);
-    // The radiance of every path is kept until its pixel is summed, so the frame is cut into batches of pattern
-    // columns whose radiance buffer fits the budget (default 12 GiB of the 288 GB).
-    uint64_t budget = (uint64_t)env_int("RT_AMD_RADIANCE_MIB", 12 * 1024) * 1024ull * 1024ull;
-    uint64_t cols = budget / ((uint64_t)P.n_pixels * sizeof(float4));
-    uint64_t max_cols = (0xFFFFFFFFull - pool.n_slots - 4096ull) / P.n_pixels; // path numbers are 32-bit
+    uint32_t slots = slots_wanted / slot_quantum * slot_quantum;
+    if (slots < slot_quantum) slots = slot_quantum;
+    if ((uint64_t)slots > total_paths) slots = (uint32_t)((total_paths + 1023ull) / 1024ull * 1024ull);
+    uint64_t cols = radiance_entries / (uint64_t)P.n_pixels;
+    uint64_t max_cols = (0xFFFFFFFFull - slots - 4096ull) / P.n_pixels; // path numbers are 32-bit
     if (cols > max_cols) cols = max_cols;
     if (cols > 0xFFFFFFull) cols = 0xFFFFFFull; // the column inside the batch travels in 24 bits of the depth word
     if (cols > n_shard_samples) cols = n_shard_samples;
-    if (cols < 1) return rt_fail(RT_EINVAL, "image too large for the radiance buffer budget");
-    st = ensure(&s->d_pattern, &s->pattern_cap, (size_t)2 * (size_t)n);
-    if (st != RT_OK) return st;
-    st = ensure(&s->d_pool, &s->pool_cap, (size_t)5 * pool.n_slots);
-    if (st != RT_OK) return st;
-    st = ensure(&s->d_radiance, &s->radiance_cap, (size_t)cols * P.n_pixels);
-    if (st != RT_OK) return st;
-    st = ensure(&s->d_redo, &s->redo_cap, (size_t)pool.n_slots);
-    if (st != RT_OK) return st;
-    pool.q = s->d_pool;
-    pool.redo = s->d_redo;
-    if (!s->side && !std::getenv("RT_AMD_NO_REDO_OVERLAP")) {
-        HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&s->join, hipEventDisableTiming));
-    }
-    HIP_TRY(hipMemcpyAsync(s->d_pattern, pattern, (size_t)2 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, stream));
+    if (cols < 1) return rt_fail(RT_EINVAL, "image too large for the radiance buffer");
+    *n_slots = slots;
+    *cols_out = (uint32_t)cols;
+    return RT_OK;
+}
+
+static int render_frame(rtScene* s, const rtCamera* camera, const float* pattern, int n, RtRenderParams& P, uint32_t n_shard_samples,
+                        const Workspace& ws, uint32_t flags, float* d_accum, hipStream_t stream) {
+    int st = RT_OK;
+    PathPool pool;
+    pool.n_slots = ws.n_slots;
+    pool.q = ws.pool;
+    pool.redo = ws.redo;
+    const uint32_t cols = ws.cols;
+    const bool overlap = ws.may_allocate && s->side && s->fork && s->join && !std::getenv("RT_AMD_NO_REDO_OVERLAP");
+    HIP_TRY(hipMemcpyAsync(ws.pattern, pattern, (size_t)2 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, stream));
     bool count = (flags & RT_FLAG_COUNTERS) != 0;
     if (count) HIP_TRY(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), stream));
     bool timing = (flags & RT_FLAG_TIMING) != 0;
-    if (timing && !s->events) {
-        s->events = new (std::nothrow) hipEvent_t[3u * BOUNCE_BATCH];
-        if (!s->events) return rt_fail(RT_ENOMEM, "out of host memory");
-        for (uint32_t i = 0; i < 3u * BOUNCE_BATCH; ++i) HIP_TRY(hipEventCreate(&s->events[i]));
-    }
     s->last_extend_s = s->last_shade_s = 0.0;
     s->last_extend_launches = s->last_shade_launches = 0;
     RtCameraDev cam;
     camera_to_dev(camera, &cam);
     uint32_t extend_blocks = (uint32_t)(s->n_cus > 0 ? s->n_cus : 256) * (uint32_t)env_int("RT_AMD_EXTEND_BLOCKS_PER_CU", 6);
     const uint32_t frame_slots = pool.n_slots;
-    for (uint32_t k0 = 0; k0 < n_shard_samples; k0 += (uint32_t)cols) {
+    for (uint32_t k0 = 0; k0 < n_shard_samples; k0 += cols) {
         pool.n_slots = frame_slots;
-        pool.q = s->d_pool;
+        pool.q = ws.pool;
         bool tail = false; // the device reported that no unstarted path is left
         const uint32_t batch = BOUNCE_BATCH;
         P.k_begin = k0;
-        P.k_end = k0 + (uint32_t)cols < n_shard_samples ? k0 + (uint32_t)cols : n_shard_samples;
+        P.k_end = k0 + cols < n_shard_samples ? k0 + cols : n_shard_samples;
         P.n_paths = (P.k_end - P.k_begin) * P.n_pixels;
         // sync[0] = slot dispenser, sync[2..] = activity flag of each bounce, then the path dispensers.  The slots
         // start with paths 0 .. n_slots-1, which is the same number of whole units from every dispenser.
@@ -362,29 +350,29 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
         if (P.n_paths > pool.n_slots) disp_start = pool.n_slots / P.n_disp;
         std::memset(s->h_init, 0, SYNC_WORDS * sizeof(uint32_t));
         for (uint32_t c = 0; c < RT_DISP_MAX; ++c) s->h_init[RT_DISP_BASE + c * RT_DISP_STRIDE] = disp_start;
-        HIP_TRY(hipMemcpyAsync(s->d_sync, s->h_init, SYNC_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(ws.sync, s->h_init, SYNC_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         // with max_depth == 0 trace() returns black without looking at the scene: no path ever writes its radiance
-        if (P.max_depth == 0) HIP_TRY(hipMemsetAsync(s->d_radiance, 0, (size_t)P.n_paths * sizeof(float4), stream));
-        rt_launch_init(&cam, s->d_pattern, &P, &pool, stream);
+        if (P.max_depth == 0) HIP_TRY(hipMemsetAsync(ws.radiance, 0, (size_t)P.n_paths * sizeof(float4), stream));
+        rt_launch_init(&cam, ws.pattern, &P, &pool, stream);
         HIP_TRY(hipGetLastError());
         // Bounce loop: the device reports after every bounce how many slots still hold a ray; the host enqueues
         // bounces in batches and stops after the first batch that ends with none.
         for (uint64_t bounce = 0;; bounce += batch) {
-            HIP_TRY(hipMemsetAsync(s->d_sync + 2, 0, BOUNCE_BATCH * sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(ws.sync + 2, 0, BOUNCE_BATCH * sizeof(uint32_t), stream));
             // The slots on hold are settled between two batches.  rt_extend_kernel leaves them alone and rt_redo_kernel
             // touches nothing else, so the two run side by side (the redo is a few lone lanes walking the tree); the
             // batch's first shade kernel waits for it.  Before a compaction, which moves the slots, it runs in line.
-            const bool compacting = tail && pool.n_slots > 4096u && !std::getenv("RT_AMD_NO_COMPACT");
+            const bool compacting = ws.may_allocate && tail && pool.n_slots > 4096u && !std::getenv("RT_AMD_NO_COMPACT");
             bool beside = false;
             if (bounce != 0) {
-                if (!compacting && s->side) {
+                if (!compacting && overlap) {
                     HIP_TRY(hipEventRecord(s->fork, stream));
                     HIP_TRY(hipStreamWaitEvent(s->side, s->fork, 0));
-                    rt_launch_redo(&s->dev, &pool, s->d_sync, s->side);
+                    rt_launch_redo(&s->dev, &pool, ws.sync, s->side);
                     HIP_TRY(hipEventRecord(s->join, s->side));
                     beside = true;
                 } else {
-                    rt_launch_redo(&s->dev, &pool, s->d_sync, stream);
+                    rt_launch_redo(&s->dev, &pool, ws.sync, stream);
                 }
             }
             // No unstarted path left: the slots run dry over the next (up to max_depth) bounces.  The ones that still
@@ -393,21 +381,21 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
                 st = ensure(&s->d_pool2, &s->pool2_cap, (size_t)5 * frame_slots);
                 if (st == RT_OK) st = ensure(&s->d_counts, &s->counts_cap, (size_t)frame_slots / 256 + 2);
                 if (st != RT_OK) return st;
-                float4* to = pool.q == s->d_pool ? s->d_pool2 : s->d_pool;
-                rt_launch_compact(&pool, to, s->d_counts, s->d_sync, stream);
+                float4* to = pool.q == ws.pool ? s->d_pool2 : ws.pool;
+                rt_launch_compact(&pool, to, s->d_counts, ws.sync, stream);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(s->h_sync + 1, s->d_sync + RT_LIVE_SLOTS, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipMemcpyAsync(s->h_sync + 1, ws.sync + RT_LIVE_SLOTS, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
                 pool.n_slots = RT_COMPACT_SLOTS(s->h_sync[1], pool.n_slots);
                 pool.q = to;
             }
             for (uint32_t b = 0; b < batch; ++b)
-                rt_launch_bounce(&s->dev, &cam, s->d_pattern, &P, &pool, extend_blocks, s->d_radiance, s->d_sync,
-                                 s->d_sync + 2u + b, s->d_counters, count, timing ? s->events + 3u * b : nullptr, stream,
+                rt_launch_bounce(&s->dev, &cam, ws.pattern, &P, &pool, extend_blocks, ws.radiance, ws.sync,
+                                 ws.sync + 2u + b, s->d_counters, count, timing ? s->events + 3u * b : nullptr, stream,
                                  (b == 0u && beside) ? s->join : nullptr);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(s->h_sync, s->d_sync + 1u + batch, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipMemcpyAsync(s->h_sync + 2, s->d_sync + RT_TAIL_FLAG, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(s->h_sync, ws.sync + 1u + batch, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(s->h_sync + 2, ws.sync + RT_TAIL_FLAG, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             if (timing) {
                 for (uint32_t b = 0; b < batch; ++b) {
@@ -423,25 +411,94 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
             if (s->h_sync[0] == 0u) break;
             tail = s->h_sync[2] != 0u;
             if (bounce > ((uint64_t)P.n_paths / pool.n_slots + 2ull) * 64ull + 4096ull)
-                return rt_fail(RT_EHIP, "rt_render_accumulate: bounce loop did not terminate");
+                return rt_fail(RT_EHIP, "bounce loop did not terminate");
         }
         if (P.n_paths > frame_slots) {
             // every path of the batch must have been handed to a slot: the counters are read back and held against
             // their limits (a path left behind would leave a stale entry in the radiance buffer, silently)
-            HIP_TRY(hipMemcpy2DAsync(s->h_sync + 8, sizeof(uint32_t), s->d_sync + RT_DISP_BASE, RT_DISP_STRIDE * sizeof(uint32_t),
+            HIP_TRY(hipMemcpy2DAsync(s->h_sync + 8, sizeof(uint32_t), ws.sync + RT_DISP_BASE, RT_DISP_STRIDE * sizeof(uint32_t),
                                      sizeof(uint32_t), P.n_disp, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             for (uint32_t c = 0; c < P.n_disp; ++c)
                 if (s->h_sync[8u + c] < rt_dispenser_limit(P.n_paths, P.n_disp, c))
-                    return rt_fail(RT_EHIP, "rt_render_accumulate: internal: path dispenser %u stopped at %u of %u", c,
-                                   s->h_sync[8u + c], rt_dispenser_limit(P.n_paths, P.n_disp, c));
+                    return rt_fail(RT_EHIP, "internal: path dispenser %u stopped at %u of %u", c, s->h_sync[8u + c],
+                                   rt_dispenser_limit(P.n_paths, P.n_disp, c));
         }
-        rt_launch_sum(&P, s->d_radiance, d_accum, k0 == 0u ? 1 : 0, stream);
+        rt_launch_sum(&P, ws.radiance, d_accum, k0 == 0u ? 1 : 0, stream);
         HIP_TRY(hipGetLastError());
     }
-    s->last_stream = stream;
-    s->last_paths = total_paths;
+    s->last_paths = (uint64_t)P.n_pixels * n_shard_samples;
     return RT_OK;
+}
+
+// checks shared by the two accumulate entry points; *empty: the shard holds no pattern column (d_accum was zeroed)
+static int accumulate_prologue(const char* who, rtScene* s, const rtCamera* camera, const float* pattern, int n, int sample_first,
+                               int sample_stride, const float background[3], int width, int height, int max_depth, uint64_t seed,
+                               float* d_accum, hipStream_t stream, RtRenderParams* P, uint32_t* n_shard_samples, bool* empty) {
+    *empty = false;
+    if (!s || !camera || !pattern || !d_accum) return rt_fail(RT_EINVAL, "%s: null argument", who);
+    if (n <= 0 || sample_first < 0 || sample_stride <= 0)
+        return rt_fail(RT_EINVAL, "%s: need n > 0, sample_first >= 0, sample_stride > 0", who);
+    int st = fill_params(background, width, height, max_depth, seed, P);
+    if (st != RT_OK) return st;
+    HIP_TRY(hipSetDevice(s->device));
+    if (sample_first >= n) { // an empty shard (more shards than pattern columns) contributes a zero sum
+        HIP_TRY(hipMemsetAsync(d_accum, 0, P->image_floats * sizeof(float), stream));
+        s->last_paths = 0;
+        *empty = true;
+        return RT_OK;
+    }
+    st = ensure_reach(s, camera_reach(camera));
+    if (st != RT_OK) return st;
+    P->sample_first = sample_first;
+    P->sample_stride = sample_stride;
+    *n_shard_samples = (uint32_t)((n - sample_first + sample_stride - 1) / sample_stride);
+    return RT_OK;
+}
+
+int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* pattern, int n, int sample_first,
+                         int sample_stride, const float background[3], int width, int height, int max_depth,
+                         uint64_t seed, uint32_t flags, float* d_accum, void* stream_) {
+    RtRenderParams P;
+    uint32_t n_shard_samples = 0;
+    bool empty = false;
+    hipStream_t stream = (hipStream_t)stream_;
+    int st = accumulate_prologue("rt_render_accumulate", s, camera, pattern, n, sample_first, sample_stride, background, width,
+                                 height, max_depth, seed, d_accum, stream, &P, &n_shard_samples, &empty);
+    if (st != RT_OK || empty) return st;
+    // Slots in flight: enough rays per launch to fill the machine many times over.  Default 4 Mi: the four live planes of
+    // the path pool (64 bytes per slot) then just stay inside the 256 MB Infinity Cache between the kernel that writes them
+    // and the one that reads them; throughput falls by 6 % right above that and does not come back before 10 Mi slots.
+    // The radiance of every path is kept until its pixel is summed, so the frame is cut into batches of pattern
+    // columns whose radiance buffer fits the budget (default 12 GiB of the 288 GB).
+    Workspace ws{};
+    const uint64_t budget = (uint64_t)env_int("RT_AMD_RADIANCE_MIB", 12 * 1024) * 1024ull * 1024ull;
+    st = plan_frame(P, n_shard_samples, (uint32_t)env_int("RT_AMD_SLOTS", 4 * 1024 * 1024), budget / sizeof(float4), &ws.n_slots, &ws.cols);
+    if (st != RT_OK) return st;
+    st = ensure(&s->d_pattern, &s->pattern_cap, (size_t)2 * (size_t)n);
+    if (st != RT_OK) return st;
+    st = ensure(&s->d_pool, &s->pool_cap, (size_t)5 * ws.n_slots);
+    if (st != RT_OK) return st;
+    st = ensure(&s->d_radiance, &s->radiance_cap, (size_t)ws.cols * P.n_pixels);
+    if (st != RT_OK) return st;
+    st = ensure(&s->d_redo, &s->redo_cap, (size_t)ws.n_slots);
+    if (st != RT_OK) return st;
+    if (!(s->side && s->fork && s->join) && !std::getenv("RT_AMD_NO_REDO_OVERLAP")) {
+        // each handle is created once and kept; a failure part-way leaves the others as they are (null = not created)
+        if (!s->side) HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        if (!s->fork) HIP_TRY(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
+        if (!s->join) HIP_TRY(hipEventCreateWithFlags(&s->join, hipEventDisableTiming));
+    }
+    if ((flags & RT_FLAG_TIMING) && s->n_events < 3u * BOUNCE_BATCH) {
+        if (!s->events) {
+            s->events = new (std::nothrow) hipEvent_t[3u * BOUNCE_BATCH]();
+            if (!s->events) return rt_fail(RT_ENOMEM, "out of host memory");
+        }
+        for (; s->n_events < 3u * BOUNCE_BATCH; ++s->n_events) HIP_TRY(hipEventCreate(&s->events[s->n_events]));
+    }
+    ws.pattern = s->d_pattern; ws.pool = s->d_pool; ws.redo = s->d_redo; ws.radiance = s->d_radiance; ws.sync = s->d_sync;
+    ws.may_allocate = true;
+    return render_frame(s, camera, pattern, n, P, n_shard_samples, ws, flags, d_accum, stream);
 }
 
 int rt_finalize(rtScene* s, const float* d_accum, int n_total, int width, int height, float* d_out, void* stream_) {
@@ -467,7 +524,7 @@ int rt_finalize_rgb8(rtScene* s, const float* d_accum, int n_total, int width, i
 int rt_get_counters(rtScene* s, rtStats* stats) {
     if (!s || !stats) return rt_fail(RT_EINVAL, "rt_get_counters: null argument");
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    HIP_TRY(hipDeviceSynchronize()); // not the stream of the last call: the caller may have destroyed it since
     unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(c, s->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     std::memset(stats, 0, sizeof(*stats));
@@ -493,19 +550,21 @@ int rt_render(rtScene* s, const rtCamera* camera, const float* pattern, int n, c
     size_t image_floats = (size_t)3 * (size_t)width * (size_t)height;
     int st = ensure(&s->d_accum, &s->accum_cap, image_floats);
     if (st != RT_OK) return st;
-    hipEvent_t e0, e1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct EventGuard { // the two events are released on every way out
+        hipEvent_t &a, &b;
+        ~EventGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } guard{e0, e1};
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, nullptr));
     st = rt_render_accumulate(s, camera, pattern, n, 0, 1, background, width, height, max_depth, seed, flags, s->d_accum, nullptr);
     if (st == RT_OK) st = rt_finalize(s, s->d_accum, n, width, height, s->d_accum, nullptr);
-    if (st != RT_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st; }
+    if (st != RT_OK) return st;
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipMemcpy(out, s->d_accum, image_floats * sizeof(float), hipMemcpyDeviceToHost));
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     if (stats) {
         if (flags & (RT_FLAG_COUNTERS | RT_FLAG_TIMING)) {
             st = rt_get_counters(s, stats);

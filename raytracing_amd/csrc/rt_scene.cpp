@@ -426,7 +426,11 @@ struct Builder {
             if (!valid_obj(oi) || D.objects[oi].kind != RT_MESH) return fail(RT_EINVAL, "mesh tree over a non-mesh object");
             int mi = D.objects[oi].aux;
             if (mi < 0 || mi >= D.n_meshes) return fail(RT_EINVAL, "mesh index out of range");
-            return collect_tris(T, D.meshes[mi], top_pos[(size_t)oi], T.node_left[id - 1], depth + 1,
+            const rtMesh& M = D.meshes[mi];
+            if (M.n_triangles < 0 || M.n_vertices < 0 || M.n_materials < 0) return fail(RT_EINVAL, "mesh with a negative count");
+            if ((M.n_triangles > 0 && (!M.indices || !M.vertices)) || (M.n_materials > 0 && !M.materials) || (M.n_triangles > 0 && M.n_materials == 0))
+                return fail(RT_EINVAL, "mesh has a null table with a non-zero count");
+            return collect_tris(T, M, top_pos[(size_t)oi], T.node_left[id - 1], depth + 1,
                                 rank_base + rank_offset[(size_t)(pos - 1)], tree);
         }
         return collect_mesh_level(T, T.node_left[id - 1], depth + 1, rank_base, rank_offset, tree) &&

@@ -140,6 +140,10 @@ class DeviceScene:
         later call takes back through `state=` to go on where it stopped.  After the last shard the image equals
         render()'s up to the order of the float32 sums."""
         import torch
+        if not torch.cuda.is_available():
+            raise ffi.RtError("render_progressive keeps its accumulators in torch tensors and torch sees no GPU; if the "
+                              "library was loaded first, import torch before raytracing_amd (torch ships its own HIP "
+                              "runtime, which cannot start after the system's)")
         pat, n = _pattern(pattern)
         passes = max(1, min(int(passes), n))
         dev = torch.device("cuda", torch.cuda.current_device())

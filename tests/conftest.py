@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# torch first: it brings its own copy of the HIP runtime, and a process that has already initialised the system's copy
+# (through librt_amd.so) cannot initialise torch's afterwards ("No HIP GPUs are available").  Loaded in this order the
+# library binds to the copy torch loaded, and the tests that hold accumulators in torch tensors work in any selection.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

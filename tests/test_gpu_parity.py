@@ -204,10 +204,10 @@ def test_sample_sharding_sums_to_the_full_frame(scenes):
     W, H = 64, 48
     full, _ = dev.render(cam, pat, bg, W, H)
     total = torch.zeros(3 * W * H, dtype=torch.float32, device="cuda")
-    for g in (3,):
+    for g in (3, 16):                  # 16 shards of 12 columns: the last four are empty and must contribute zero
         total.zero_()
         for r in range(g):
-            acc = torch.zeros(3 * W * H, dtype=torch.float32, device="cuda")
+            acc = torch.full((3 * W * H,), 7.0, dtype=torch.float32, device="cuda")
             dev.accumulate(cam, pat, bg, W, H, acc.data_ptr(), sample_first=r, sample_stride=g,
                            stream=torch.cuda.current_stream().cuda_stream)
             total += acc
