@@ -189,6 +189,23 @@ int rt_render_accumulate(rtScene* scene, const rtCamera* camera, const float* pa
                          int sample_stride, const float background[3], int width, int height, int max_depth,
                          uint64_t seed, uint32_t flags, float* d_accum, void* stream);
 int rt_finalize(rtScene* scene, const float* d_accum, int n_total, int width, int height, float* d_out, void* stream);
+/* No counterpart in the reference.  rt_render_accumulate for callers that cannot allocate device memory: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments (no flags), same result
+ * bit for bit, but the path pool, the list of slots on hold, the dispenser words, the pattern copy and the per-path
+ * radiance buffer live in a fixed scratch array inside the library's code object (53 MiB, held by
+ * every GPU the library is loaded on until the process ends), so the call makes no hipMalloc / hipFree and creates no
+ * stream or event.  Limits (RT_EINVAL beyond them): n <= RT_STATIC_MAX_COLUMNS pattern columns, width * height <=
+ * RT_STATIC_MAX_PIXELS; the pool has RT_STATIC_SLOTS slots, so large frames run slower than through
+ * rt_render_accumulate.  Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two streams, two
+ * threads, two scenes) race; calls on different GPUs do not.  The scene must have been created by rt_scene_create
+ * (which allocates), and a camera far outside the scene makes the call rebuild the node boxes on the host first, like
+ * rt_render_accumulate (a synchronous copy into memory the handle already owns). */
+#define RT_STATIC_SLOTS (256u * 1024u)
+#define RT_STATIC_MAX_COLUMNS 16384u
+#define RT_STATIC_MAX_PIXELS (2u * 1024u * 1024u)
+int rt_render_accumulate_static(rtScene* scene, const rtCamera* camera, const float* pattern, int n, int sample_first,
+                                int sample_stride, const float background[3], int width, int height, int max_depth,
+                                uint64_t seed, float* d_accum, void* stream);
 /* counters of the last rt_render_accumulate with RT_FLAG_COUNTERS (synchronises the stream) */
 int rt_get_counters(rtScene* scene, rtStats* stats);
 

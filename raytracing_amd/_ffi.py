@@ -16,6 +16,7 @@ RT_BOX, RT_TRANSFORM, RT_CONSTANT_MEDIUM, RT_BVH, RT_MESH = 6, 7, 8, 9, 10
 RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_IMAGE, RT_TEX_NOISE_MARBLE, RT_TEX_NOISE_SCALAR = 0, 1, 2, 3, 4
 RT_FLAG_COUNTERS = 1
 RT_FLAG_TIMING = 2
+RT_STATIC_SLOTS, RT_STATIC_MAX_COLUMNS, RT_STATIC_MAX_PIXELS = 256 * 1024, 16384, 2 * 1024 * 1024
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -110,6 +111,8 @@ SYMBOLS = {
                             C.c_uint64, C.c_uint32, c_f32p, C.POINTER(rtStats)]),
     "rt_render_accumulate": (C.c_int, [C.c_void_p, C.POINTER(rtCamera), c_f32p, C.c_int, C.c_int, C.c_int, c_f32p,
                                        C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "rt_render_accumulate_static": (C.c_int, [C.c_void_p, C.POINTER(rtCamera), c_f32p, C.c_int, C.c_int, C.c_int, c_f32p,
+                                              C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rt_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rt_get_counters": (C.c_int, [C.c_void_p, C.POINTER(rtStats)]),
     "rt_trace_rays": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.c_float, C.c_float, C.c_uint64, c_i32p, c_i32p,

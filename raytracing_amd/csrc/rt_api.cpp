@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -280,7 +281,8 @@ int rt_scene_destroy(rtScene* s) {
     return RT_OK;
 }
 
-// ---- the frame loop of rt_render_accumulate, over buffers the caller of render_frame provides
+// ---- the frame loop shared by rt_render_accumulate (buffers owned by the handle, grown on demand) and
+// rt_render_accumulate_static (buffers carved out of the file-scope scratch array; nothing is allocated)
 struct Workspace {
     float* pattern;          // 2 * n floats
     float4* pool;            // 5 planes of n_slots entries
@@ -499,6 +501,69 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
     ws.pattern = s->d_pattern; ws.pool = s->d_pool; ws.redo = s->d_redo; ws.radiance = s->d_radiance; ws.sync = s->d_sync;
     ws.may_allocate = true;
     return render_frame(s, camera, pattern, n, P, n_shard_samples, ws, flags, d_accum, stream);
+}
+
+// ---- rt_render_accumulate_static: the same frame loop out of a fixed scratch array, for callers that cannot allocate.
+// The array is device memory of the code object: every GPU the library runs on holds its own copy, at its own
+// address, from the moment the code object is loaded there until the process ends.  Host code never uses the array's name
+// as an address (on the host it is a stand-in); the address on a device is asked for once, with that device current
+// (static_scratch), and kept.
+#define RT_STATIC_SYNC_BYTES (((size_t)RT_SYNC_WORDS * sizeof(uint32_t) + 255u) / 256u * 256u)
+#define RT_STATIC_PATTERN_BYTES ((size_t)2 * RT_STATIC_MAX_COLUMNS * sizeof(float))
+#define RT_STATIC_REDO_BYTES ((size_t)RT_STATIC_SLOTS * sizeof(uint32_t))
+#define RT_STATIC_POOL_BYTES ((size_t)5 * RT_STATIC_SLOTS * sizeof(float4))
+#define RT_STATIC_RADIANCE_BYTES ((size_t)RT_STATIC_MAX_PIXELS * sizeof(float4))
+#define RT_STATIC_SCRATCH_BYTES (RT_STATIC_SYNC_BYTES + RT_STATIC_PATTERN_BYTES + RT_STATIC_REDO_BYTES + RT_STATIC_POOL_BYTES + RT_STATIC_RADIANCE_BYTES)
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+
+#define RT_MAX_DEVICES 64
+static unsigned char* g_scratch_ptr[RT_MAX_DEVICES]; // per device: where `scratch` lives there; null = not asked yet
+static std::mutex g_scratch_mutex;
+
+// the address of `scratch` on `device`, which must be the current device
+static int static_scratch(int device, unsigned char** out) {
+    if (device < 0 || device >= RT_MAX_DEVICES) return rt_fail(RT_EINVAL, "device %d: only devices 0..%d can use the static scratch", device, RT_MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return rt_fail(RT_EHIP, "hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(e));
+        g_scratch_ptr[device] = (unsigned char*)p;
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+
+int rt_render_accumulate_static(rtScene* s, const rtCamera* camera, const float* pattern, int n, int sample_first,
+                                int sample_stride, const float background[3], int width, int height, int max_depth,
+                                uint64_t seed, float* d_accum, void* stream_) {
+    if (n > (int)RT_STATIC_MAX_COLUMNS)
+        return rt_fail(RT_EINVAL, "rt_render_accumulate_static: %d pattern columns, the static scratch holds %u at most", n, RT_STATIC_MAX_COLUMNS);
+    if (width > 0 && height > 0 && (uint64_t)width * (uint64_t)height > RT_STATIC_MAX_PIXELS)
+        return rt_fail(RT_EINVAL, "rt_render_accumulate_static: %d x %d pixels, the static scratch holds %u at most", width, height, RT_STATIC_MAX_PIXELS);
+    RtRenderParams P;
+    uint32_t n_shard_samples = 0;
+    bool empty = false;
+    hipStream_t stream = (hipStream_t)stream_;
+    int st = accumulate_prologue("rt_render_accumulate_static", s, camera, pattern, n, sample_first, sample_stride, background,
+                                 width, height, max_depth, seed, d_accum, stream, &P, &n_shard_samples, &empty);
+    if (st != RT_OK || empty) return st;
+    unsigned char* base = nullptr;
+    st = static_scratch(s->device, &base); // (the device is current: accumulate_prologue set it)
+    if (st != RT_OK) return st;
+    Workspace ws{};
+    ws.sync = (uint32_t*)base;
+    ws.pattern = (float*)(base + RT_STATIC_SYNC_BYTES);
+    ws.redo = (uint32_t*)(base + RT_STATIC_SYNC_BYTES + RT_STATIC_PATTERN_BYTES);
+    ws.pool = (float4*)(base + RT_STATIC_SYNC_BYTES + RT_STATIC_PATTERN_BYTES + RT_STATIC_REDO_BYTES);
+    ws.radiance = (float4*)(base + RT_STATIC_SYNC_BYTES + RT_STATIC_PATTERN_BYTES + RT_STATIC_REDO_BYTES + RT_STATIC_POOL_BYTES);
+    ws.may_allocate = false;
+    st = plan_frame(P, n_shard_samples, RT_STATIC_SLOTS, RT_STATIC_MAX_PIXELS, &ws.n_slots, &ws.cols);
+    if (st != RT_OK) return st;
+    // Everything the kernels expect to start from a known state is written before it is read: the sync words are copied
+    // in whole before every column batch, rt_init_kernel writes every slot of the pool, the list of slots on hold is
+    // counted from zero in the sync words, and every path of a batch writes its radiance entry before the sum reads it.
+    return render_frame(s, camera, pattern, n, P, n_shard_samples, ws, 0u, d_accum, stream);
 }
 
 int rt_finalize(rtScene* s, const float* d_accum, int n_total, int width, int height, float* d_out, void* stream_) {

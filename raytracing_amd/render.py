@@ -122,6 +122,17 @@ class DeviceScene:
                                                  sample_stride, ffi.fptr(bg), width, height, max_depth, seed, flags,
                                                  C.c_void_p(d_accum), C.c_void_p(stream or 0)))
 
+    def accumulate_static(self, camera, pattern, background, width, height, d_accum, sample_first=0, sample_stride=1,
+                          max_depth=50, seed=DEFAULT_SEED, stream=None):
+        """accumulate() without any device allocation (rt_render_accumulate_static): the working buffers are a fixed
+        array inside the library; at most RT_STATIC_MAX_COLUMNS pattern columns and RT_STATIC_MAX_PIXELS pixels."""
+        pat, n = _pattern(pattern)
+        bg = np.asarray(background, dtype=F)
+        cam = camera_record(camera)
+        ffi.check(ffi.lib().rt_render_accumulate_static(self.handle, C.byref(cam), ffi.fptr(pat), n, sample_first,
+                                                        sample_stride, ffi.fptr(bg), width, height, max_depth, seed,
+                                                        C.c_void_p(d_accum), C.c_void_p(stream or 0)))
+
     def finalize(self, d_accum, n_total, width, height, d_out, stream=None):
         ffi.check(ffi.lib().rt_finalize(self.handle, C.c_void_p(d_accum), n_total, width, height,
                                         C.c_void_p(d_out), C.c_void_p(stream or 0)))
