@@ -207,6 +207,7 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     if (st == RT_OK) st = upload(s, H.perlin_vec, &s->dev.perlin_vec);
     if (st == RT_OK) st = upload(s, H.perlin_perm, &s->dev.perlin_perm);
     if (st == RT_OK) st = upload(s, H.media, &s->dev.media);
+    if (st == RT_OK) st = upload(s, H.media_group, &s->dev.media_group);
     if (st == RT_OK) st = upload(s, H.prim_top, &s->dev.prim_top);
     if (st == RT_OK) st = upload(s, H.prim_sub, &s->dev.prim_sub);
     if (st == RT_OK) {
@@ -229,6 +230,7 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     s->dev.surface_size = H.surface_size;
     s->dev.n_media = (uint32_t)H.media.size();
     s->dev.n_buckets = (uint32_t)H.bucket_base.size();
+    s->dev.first_group_base = H.bucket_base.empty() ? 0u : H.bucket_base[0];
     s->dev.nested = H.nested ? 1u : 0u;
     s->dev.textured = H.textured ? 1u : 0u;
     *out = s;
@@ -370,11 +372,11 @@ static int render_frame(rtScene* s, const rtCamera* camera, const float* pattern
                 if (!compacting && overlap) {
                     HIP_TRY(hipEventRecord(s->fork, stream));
                     HIP_TRY(hipStreamWaitEvent(s->side, s->fork, 0));
-                    rt_launch_redo(&s->dev, &pool, ws.sync, s->side);
+                    rt_launch_redo(&s->dev, &P, &pool, ws.sync, s->side);
                     HIP_TRY(hipEventRecord(s->join, s->side));
                     beside = true;
                 } else {
-                    rt_launch_redo(&s->dev, &pool, ws.sync, stream);
+                    rt_launch_redo(&s->dev, &P, &pool, ws.sync, stream);
                 }
             }
             // No unstarted path left: the slots run dry over the next (up to max_depth) bounces.  The ones that still

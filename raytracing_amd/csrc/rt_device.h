@@ -70,6 +70,7 @@ struct DevScene {
     const float* perlin_vec;     // 768 floats per perlin
     const int32_t* perlin_perm;  // 768 ints per perlin (x, y, z)
     const uint32_t* media;       // the constant media (primitive indices) in descending rank
+    const uint32_t* media_group; // ... and the type group of each (position in the SceneManager tuple)
     const uint32_t* bucket_base; // lowest rank of every type group of the SceneManager, in its order (descending ranks)
     const int32_t* prim_top;     // per primitive: position in the world vector (reported prim_id)
     const int32_t* prim_sub;     // per primitive: reported sub id base (triangle id / nested object index)
@@ -85,6 +86,7 @@ struct DevScene {
     uint32_t textured;     // 1 if any texture is not a SolidColor
     uint32_t n_media;      // entries in `media`
     uint32_t n_buckets;    // entries in `bucket_base`
+    uint32_t first_group_base; // bucket_base[0]: a rank at or above it belongs to the first type group
 };
 
 #endif

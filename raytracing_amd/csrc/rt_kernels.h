@@ -68,7 +68,7 @@ void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, const float* d_
                       unsigned long long* d_counters, bool count, hipEvent_t* timing, hipStream_t stream,
                       hipEvent_t before_shade = nullptr); // before_shade: the shade kernel waits for this event (rt_redo_kernel on another stream)
 // settles the slots that the shade kernel put on hold since the last call; to be enqueued between batches of bounces
-void rt_launch_redo(const DevScene* S, const PathPool* pool, uint32_t* d_sync, hipStream_t stream);
+void rt_launch_redo(const DevScene* S, const RtRenderParams* P, const PathPool* pool, uint32_t* d_sync, hipStream_t stream);
 // The slots of `from` that hold a ray, moved to the front of the pool `to` (same order), which has
 // RT_COMPACT_SLOTS(their number, from->n_slots) slots, the others marked empty; d_sync[RT_LIVE_SLOTS] receives their
 // number.  d_counts: scratch, from->n_slots / 256 + 2 words.

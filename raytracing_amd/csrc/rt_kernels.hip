@@ -421,7 +421,7 @@ __device__ __forceinline__ bool ref_box_pass(float4 b0, float4 b1, f3 o, f3 d, f
 // Does the reference reach primitive `prim` with the ray (o, d) as cast?  xf: index + 1 of the Transform around the
 // nested tree the primitive belongs to, if any.  t_max: the bound the reference has at that moment -- the one the ray
 // was cast with when the question is only whether the box is passed at all (hit_stands says when that is enough), the
-// closest distance so far of the primitive's tree when the reference's sequence is played (surface_again).
+// closest distance so far of the primitive's tree when the reference's sequence is played (front_sequence).
 // b0, b1: the first two words of the primitive's record in prim_box (loaded by the caller, as early as it can)
 // near_up: upper bound of the distance at which the ray enters the innermost of those boxes.  skip_outer: the outer box
 // is known to have been passed (the walk is already inside that nested tree).
@@ -470,13 +470,9 @@ __device__ __forceinline__ float ref_box_near(float4 b0, float4 b1, f3 o, f3 d, 
 // primitive's own box: then whatever the reference met before lies further away and cannot have culled that box, and
 // nothing met later is closer.  A sphere's hit can lie in front of its box (the sphere test reports points up to
 // sqrt(1.4e-6) |o - c| off the sphere); the other shapes report points of their box up to the last bit.
-__device__ __forceinline__ bool hit_stands(const DevScene& S, uint32_t prim, uint32_t xf, f3 o, f3 d, float t_min, float t_max, float t) {
+__device__ __forceinline__ float ref_entry(const DevScene& S, uint32_t prim, uint32_t xf, f3 o, f3 d, float t_min) {
+    // the distance at which the ray enters the primitive's box(es), as the reference computes it (src/bounding_box.jl:20-67)
     const float4* b = S.prim_box + 4u * prim;
-    const uint32_t kind = S.prims[3u * prim].x & 15u;
-    float near_up;
-    if (!ref_reaches<false>(S, prim, b[0], b[1], xf, o, d, t_min, t_max, near_up)) return false;
-    if (!(kind <= DP_MOVING_SPHERE && t < near_up)) return true;
-    // in front of the upper bound: now the entry distances as the reference computes them (src/bounding_box.jl:20-67)
     const uint32_t flags = __float_as_uint(b[1].z);
     float near = t_min;
     if (flags & RT_BOX_OUTER) near = ref_box_near(b[0], b[1], o, d, near);
@@ -488,7 +484,16 @@ __device__ __forceinline__ bool hit_stands(const DevScene& S, uint32_t prim, uin
         }
         near = fmaxf(near, ref_box_near(b[2], b[3], o, d, t_min));
     }
-    return !(t < near);
+    return near;
+}
+__device__ __forceinline__ bool hit_stands(const DevScene& S, uint32_t prim, uint32_t xf, f3 o, f3 d, float t_min, float t_max, float t) {
+    const float4* b = S.prim_box + 4u * prim;
+    const uint32_t kind = S.prims[3u * prim].x & 15u;
+    float near_up;
+    if (!ref_reaches<false>(S, prim, b[0], b[1], xf, o, d, t_min, t_max, near_up)) return false;
+    if (!(kind <= DP_MOVING_SPHERE && t < near_up)) return true;
+    // in front of the upper bound: now the entry distances as the reference computes them
+    return !(t < ref_entry(S, prim, xf, o, d, t_min));
 }
 template <bool MISSES>
 __device__ __forceinline__ bool ref_reaches(const DevScene& S, uint32_t prim, uint32_t xf, f3 o, f3 d, float t_min, float t_max) {
@@ -680,32 +685,77 @@ __device__ __forceinline__ void node_step(const DevScene& S, const BoxRay& R, fl
     leaf = (hit && is_leaf) ? (link & ~RT_NODE_LEAF) : 0u;
 }
 
+// type group (position in the SceneManager tuple) of a tie-break rank: the groups hold descending ranges of ranks
+__device__ __forceinline__ uint32_t group_of(const DevScene& S, uint32_t rank) {
+    uint32_t g = 0u;
+    while (g + 1u < S.n_buckets && rank < S.bucket_base[g]) ++g;
+    return g;
+}
+// One step of the reduction of hit(::SceneManager) (src/scene_manager.jl:40-52): `x` is what type group `g` returned.
+// The first group's result is taken as it is; a later one replaces the hit held only if it is closer, and only then
+// does closest_t -- the bound the following groups are given -- change.
+__device__ __forceinline__ void reduce_group(Closest& held, float& closest_t, const Closest& x, bool first_group) {
+    if (first_group) held = x;
+    else if (!(held.t <= x.t)) { held = x; closest_t = x.t; }
+}
 // The constant media of the scene for a ray whose closest surface is already in `best` (best.t = INF: none; best.rank
 // must be the surface's rank).  The reference meets the objects of a scene in a fixed order -- type group after type
 // group, inside a group in the order of its tree walk -- and tests each with the closest distance found so far as t_max
 // (src/scene_manager.jl:40-53, src/BVH.jl:22-53); for a medium that bound cuts the path through the boundary
 // (src/constant_medium.jl:36-44), so it matters what was found before it.  Ranks are that order (higher = met earlier):
-// the media are taken in descending rank, each with the bound the reference would have had -- the closest medium so
-// far, and the surface only if it ranks higher.  Every lane of a wave meets the same medium in the same step.
-// (The media are few -- a scene-wide fog, a smoke box or two -- so they are a list, not a tree.)
-__device__ __forceinline__ void media_closest(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max,
+// the media are taken in descending rank and the surface is put in where its rank falls, through the reference's own
+// reduction: inside a group the bound is the closest medium of the group so far, between the groups it is closest_t,
+// which the first group's hit never sets.  (Surfaces other than the closest one are left out: what they could add is a
+// tighter bound, and a tighter bound only turns down hits that lose anyway, see below.)  Every lane of a wave meets
+// the same medium in the same step.  (The media are few -- a scene-wide fog, a smoke box or two -- so they are a list.)
+//
+// Returns false when this is not certain to be the reference's answer: a medium was hit in front of its own leaf box
+// (only a sphere boundary does that, from far away: the sphere test reports points up to sqrt(1.4e-6) |o - c| off the
+// sphere).  The reference tests that box with the bound it has at that moment, and a bound tighter than the one used
+// here -- set by a surface of an earlier group that is not the closest one -- can cull the box although the hit lies in
+// front of the bound.  For a hit inside its box that cannot matter: a bound that culls the box lies in front of the hit.
+// The caller then plays the reference's whole sequence (reference_sequence).
+__device__ __forceinline__ bool media_closest(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max,
                                               const RngKey& key, Closest& best) {
-    Closest medium = {INF, 0xFFFFFFFFu, 0u, 0u};
-    float t_medium = INF;
+    const Closest none = {INF, 0xFFFFFFFFu, 0u, 0u};
+    Closest held = none, local = none;
+    float closest_t = t_max;
+    uint32_t group = 0xFFFFFFFFu;    // type group of the media being walked (kept by the host next to the list)
+    bool surface_in = best.t == INF; // (no surface: nothing to put in)
+    const bool surface_first = best.rank >= S.first_group_base; // the surface belongs to the first type group
+    bool certain = true;
 #pragma unroll 1
     for (uint32_t k = 0; k < S.n_media; ++k) {
-        const uint32_t prim = S.media[k];
+        const uint32_t prim = S.media[k], g = S.media_group[k];
         uint4 head;
         Geom G;
         load_prim(S, prim, head, G);
-        float lim = fminf(t_medium, t_max);
-        if (best.rank > head.z) lim = fminf(lim, best.t);
-        if (!ref_reaches<true>(S, prim, 0u, o, d, t_min, lim)) continue;
-        float t = medium_t(S, head.x, G.g, o, d, time, t_min, lim, key);
-        consider(medium, t_medium, t, prim, ((head.x >> 8) << 3) | ((head.x & DP_TYPE_MASK) << 24), head.z);
+        const float4* bx = S.prim_box + 4u * prim;
+        const float4 b0 = bx[0], b1 = bx[1];
+        if (!surface_in && best.rank > head.z) { // the surface's group comes before this medium's
+            if (group != 0xFFFFFFFFu) reduce_group(held, closest_t, local, group == 0u);
+            group = 0xFFFFFFFFu;
+            reduce_group(held, closest_t, best, surface_first);
+            surface_in = true;
+        }
+        if (g != group) {
+            if (group != 0xFFFFFFFFu) reduce_group(held, closest_t, local, group == 0u);
+            group = g;
+            local = none;
+        }
+        const float lim = fminf(closest_t, local.t);
+        float near_up;
+        if (!ref_reaches<true>(S, prim, b0, b1, 0u, o, d, t_min, lim, near_up)) continue;
+        const float t = medium_t(S, head.x, G.g, o, d, time, t_min, lim, key);
+        if (!(t < local.t)) continue;
+        // in front of the upper bound of the entry distance: now the distance as the reference computes it
+        if ((head.x & 15u) == DP_SPHERE && t < near_up && t < ref_box_near(b0, b1, o, d, t_min)) certain = false;
+        local.t = t; local.prim = prim; local.sx = ((head.x >> 8) << 3) | ((head.x & DP_TYPE_MASK) << 24); local.rank = head.z;
     }
-    float unused = INF;
-    consider(best, unused, medium.t, medium.prim, medium.sx, medium.rank);
+    if (group != 0xFFFFFFFFu) reduce_group(held, closest_t, local, group == 0u);
+    if (!surface_in) reduce_group(held, closest_t, best, surface_first);
+    best = held;
+    return certain;
 }
 
 // back out of a nested tree (its walk is over): restore the outer ray
@@ -785,22 +835,7 @@ __device__ __forceinline__ int wave_vote(bool ws, bool wl, bool wh, const Vote& 
     return 0;
 }
 
-// The pieces of the scene a surface walk needs, as plain values: what surface_again takes instead of the whole record.
-struct WalkScene {
-    const uint4* nodes;
-    const uint4* prims;
-    const float4* prim_box;
-    const float4* prim_inv;
-    const float* xforms;
-    const uint32_t* bucket_base;
-    uint32_t n_nodes, surface_root, surface_size, far_set, n_buckets;
-    float node_scale, inv_node_scale, cx, cy, cz, radius2;
-};
-__device__ __forceinline__ WalkScene walk_scene(const DevScene& S) {
-    return WalkScene{S.nodes, S.prims, S.prim_box, S.prim_inv, S.xforms, S.bucket_base, S.n_nodes, S.surface_root, S.surface_size,
-                     S.far_set, S.n_buckets, S.node_scale, S.inv_node_scale, S.centre[0], S.centre[1], S.centre[2], S.radius2};
-}
-// The hit the reference ends up with, found the way the reference finds it, over the whole scene (what surface_again
+// The hit the reference ends up with, found the way the reference finds it, over the whole scene (what front_sequence
 // falls back to when its short list overflows).  The reference meets the primitives in a fixed order (rank, higher
 // first).  Inside one type group (one tree) the closest distance so far is t_max for the boxes on the way to a primitive
 // and for its own test, and a hit is taken if it is closer (src/BVH.jl:22-53); between the groups hit(::SceneManager)
@@ -809,12 +844,10 @@ __device__ __forceinline__ WalkScene walk_scene(const DevScene& S) {
 // the last one taken that the reference reaches and hits with the bound of its group -- one walk of the device tree
 // per hit the reference takes, a handful.  The device boxes hold every point at which their primitive can report a
 // hit, so dropping the boxes that begin behind the largest bound in play loses nothing.
-__device__ __forceinline__ uint32_t group_of(const DevScene& S, uint32_t rank) {
-    uint32_t g = 0u;
-    while (g + 1u < S.n_buckets && rank < S.bucket_base[g]) ++g;
-    return g;
-}
-__device__ __forceinline__ Closest reference_sequence(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_hi) {
+// MEDIA: the constant media take part (they are objects of the scene like any other, in type groups of their own); `key`
+// then names the random stream of the ray (the draw of a medium is keyed by the medium, not by the order of the tests).
+template <bool MEDIA>
+__device__ __forceinline__ Closest reference_sequence(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_hi, const RngKey& key) {
     const f3 wo = o, wd = d; // the ray as cast
     Closest held = {INF, 0xFFFFFFFFu, 0u, 0u};  // the reduction's accumulator
     Closest local = {INF, 0xFFFFFFFFu, 0u, 0u}; // closest of the group being walked
@@ -888,6 +921,27 @@ __device__ __forceinline__ Closest reference_sequence(const DevScene& S, f3 o, f
             next_b0 = b0; next_b1 = b1;
             next_nested = (__float_as_uint(b1.z) & RT_BOX_INNER) != 0u;
         }
+        if (MEDIA) {
+            // the media between the last primitive taken and the surface found: the first one (highest rank) that the
+            // reference reaches and that is hit with the bound of its group comes before that surface
+            for (uint32_t k = 0; k < S.n_media; ++k) {
+                const uint32_t prim = S.media[k];
+                uint4 hd;
+                Geom G;
+                load_prim(S, prim, hd, G);
+                const uint32_t rank = hd.z;
+                if (rank >= below) continue;
+                if (next.prim != 0xFFFFFFFFu && rank <= next.rank) break;
+                const bool in_group = group_of(S, rank) == group;
+                const float lim = in_group ? bound : handed_on;
+                if (!ref_reaches<true>(S, prim, 0u, wo, wd, t_min, lim)) continue;
+                const float t = medium_t(S, hd.x, G.g, wo, wd, time, t_min, lim, key);
+                if (!(t < INF) || (in_group && !(t < local.t))) continue;
+                next.t = t; next.prim = prim; next.sx = ((hd.x >> 8) << 3) | ((hd.x & DP_TYPE_MASK) << 24); next.rank = rank;
+                next_nested = false;
+                break;
+            }
+        }
         const uint32_t g = next.prim != 0xFFFFFFFFu ? group_of(S, next.rank) : 0xFFFFFFFFu;
         if (g != group) { // the group is done: its closest hit goes into the reduction
             if (group == 0u) held = local;
@@ -953,42 +1007,68 @@ __device__ __forceinline__ Closest next_hit_after(const DevScene& S, f3 wo, f3 w
     return best;
 }
 
-// For a ray whose closest surface hit does not stand (hit_stands; about one ray in a hundred thousand): the hit the
-// reference ends up with.  Only the hits at the front can matter.  Let N be the closest hit that stands on its own
-// (reached, not in front of its box) and T the largest of N's distance and the box-entry distances of the hits in front
-// of their boxes found up to T.  A hit beyond T is never the last one taken (N is closer), and the bound it leaves
-// behind, being beyond T, neither culls a box nor turns down a hit among those up to T.  So the hits up to T are listed
-// (closest first, one cheap walk each), and the reference's sequence (see reference_sequence) is played over that
-// short list; if the list overflows, over the whole scene.
+// For a ray whose closest surface hit does not stand (hit_stands; about one ray in a hundred thousand), or one of whose
+// media is hit in front of its own box: the hit the reference ends up with.  Only the hits at the front can matter.
+// Let N be the closest hit that stands on its own (reached, not in front of its box) and T the largest of N's distance
+// and the box-entry distances of the hits in front of their boxes found up to T.  A hit beyond T is never the last one
+// taken (N is closer), and the bound it leaves behind, being beyond T, neither culls a box nor turns down a hit among
+// those up to T.  So the surface hits up to T are listed (closest first, one cheap walk each), the constant media -- a
+// handful, each a hit or not when nothing bounds it -- are put beside them, and the reference's sequence (see
+// reference_sequence) is played over that short list, each medium tested again with the bound it meets there; if the
+// list overflows, over the whole scene.
 #define SETTLE_LIST 6
-// first: the closest of all the hits the primitives report (what the walk of the device tree found).
-__device__ __forceinline__ Closest surface_again(WalkScene A, f3 o, f3 d, float time, float t_min, float t_hi, Closest first) {
-    DevScene S = {};
-    S.nodes = A.nodes; S.prims = A.prims; S.prim_box = A.prim_box; S.prim_inv = A.prim_inv; S.xforms = A.xforms;
-    S.n_nodes = A.n_nodes; S.surface_root = A.surface_root; S.surface_size = A.surface_size;
-    S.node_scale = A.node_scale; S.inv_node_scale = A.inv_node_scale;
-    S.far_set = A.far_set; S.centre[0] = A.cx; S.centre[1] = A.cy; S.centre[2] = A.cz; S.radius2 = A.radius2;
-    S.bucket_base = A.bucket_base; S.n_buckets = A.n_buckets;
+// first: the closest of all the hits the surfaces report (what the walk of the device tree found).  MEDIA: the scene's
+// constant media take part, `key` names the ray's random stream.
+template <bool MEDIA>
+__device__ __forceinline__ Closest front_sequence(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_hi, Closest first,
+                                                  const RngKey& key) {
     Closest list[SETTLE_LIST];
     int n = 0;
-    bool solid = false;
-    float T = t_hi, front = t_min; // front: largest box-entry distance among the hits in front of their boxes
+    float stands_t = INF;     // distance of the closest hit that stands (N)
+    float front = t_min;      // largest box-entry distance among the hits in front of their boxes
+    uint32_t media_hit = 0u;  // media (positions in S.media) that are hit when nothing bounds them
+    if (MEDIA) {
+        if (S.n_media > 32u) return reference_sequence<true>(S, o, d, time, t_min, t_hi, key);
+        for (uint32_t k = 0; k < S.n_media; ++k) {
+            const uint32_t prim = S.media[k];
+            uint4 hd;
+            Geom G;
+            load_prim(S, prim, hd, G);
+            const float4 b0 = S.prim_box[4u * prim], b1 = S.prim_box[4u * prim + 1u];
+            float near_up;
+            if (!ref_reaches<true>(S, prim, b0, b1, 0u, o, d, t_min, t_hi, near_up)) continue;
+            const float t = medium_t(S, hd.x, G.g, o, d, time, t_min, t_hi, key);
+            if (!(t < INF)) continue;
+            media_hit |= 1u << k;
+            float near = near_up;
+            bool in_front = (hd.x & 15u) == DP_SPHERE && t < near_up;
+            if (in_front) { near = ref_box_near(b0, b1, o, d, t_min); in_front = t < near; }
+            if (in_front) front = fmaxf(front, near);
+            else stands_t = fminf(stands_t, t);
+        }
+    }
+    float T = fminf(t_hi, fmaxf(stands_t, front));
     float floor_t = -INF;
     uint32_t floor_rank = 0u;
-    for (bool start = true;; start = false) {
-        if (!start && solid && !(T > floor_t)) break; // nothing in front reaches beyond the hit that stands: the list is complete
+    for (bool start = true; first.t != INF || !start; start = false) {
+        if (!start && stands_t < INF && !(T > floor_t)) break; // nothing in front reaches beyond the hit that stands: the list is complete
         const Closest c = start ? first : next_hit_after(S, o, d, time, t_min, T, floor_t, floor_rank);
         if (c.t == INF) break;
         floor_t = c.t; floor_rank = c.rank;
         const float4* b = S.prim_box + 4u * c.prim;
         float near_up;
         if (!ref_reaches<false>(S, c.prim, b[0], b[1], (c.sx >> 3) & 0x3FFFFFFu, o, d, t_min, t_hi, near_up)) continue;
-        const bool in_front = (S.prims[3u * c.prim].x & 15u) <= DP_MOVING_SPHERE && c.t < near_up;
-        if (n == SETTLE_LIST) return reference_sequence(S, o, d, time, t_min, t_hi);
+        // in front of its own box?  near_up is an upper bound of the entry distance: below it, the reference's own
+        bool in_front = (S.prims[3u * c.prim].x & 15u) <= DP_MOVING_SPHERE && c.t < near_up;
+        if (in_front) {
+            near_up = ref_entry(S, c.prim, (c.sx >> 3) & 0x3FFFFFFu, o, d, t_min);
+            in_front = c.t < near_up;
+        }
+        if (n == SETTLE_LIST) return reference_sequence<MEDIA>(S, o, d, time, t_min, t_hi, key);
         list[n++] = c;
         if (in_front) front = fmaxf(front, near_up);
-        if (!solid && !in_front) { solid = true; T = fminf(t_hi, fmaxf(c.t, front)); }
-        else if (solid) T = fminf(t_hi, fmaxf(T, front));
+        else stands_t = fminf(stands_t, c.t);
+        T = fminf(t_hi, fmaxf(stands_t, front));
     }
     // The reference's sequence over the list, highest rank first.  Inside one type group (one tree) the bound shrinks
     // with every hit taken (src/BVH.jl:36-47).  Between the groups, hit(::SceneManager) (src/scene_manager.jl:40-52)
@@ -1000,11 +1080,19 @@ __device__ __forceinline__ Closest surface_again(WalkScene A, f3 o, f3 d, float 
     uint32_t group = 0xFFFFFFFFu, below = 0xFFFFFFFFu;
     float4 local_b0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), local_b1 = local_b0;
     bool local_nested = false;
-    for (int round = 0; round <= n; ++round) {
-        int pick = -1;
-        for (int k = 0; k < n && round < n; ++k)
-            if (list[k].rank < below && (pick < 0 || list[k].rank > list[pick].rank)) pick = k;
-        const uint32_t g = pick >= 0 ? group_of(S, list[pick].rank) : 0xFFFFFFFFu;
+    for (;;) {
+        int pick = -1;       // list entry with the highest rank still to come ...
+        uint32_t pick_rank = 0u;
+        for (int k = 0; k < n; ++k)
+            if (list[k].rank < below && (pick < 0 || list[k].rank > pick_rank)) { pick = k; pick_rank = list[k].rank; }
+        int medium = -1;     // ... or the medium that comes before it
+        if (MEDIA)
+            for (uint32_t k = 0; k < S.n_media; ++k) {
+                const uint32_t rank = S.prims[3u * S.media[k]].z;
+                if ((media_hit >> k & 1u) && rank < below && ((pick < 0 && medium < 0) || rank > pick_rank)) { medium = (int)k; pick_rank = rank; }
+            }
+        const bool any = pick >= 0 || medium >= 0;
+        const uint32_t g = any ? group_of(S, pick_rank) : 0xFFFFFFFFu;
         if (g != group) { // the group is done: its closest hit goes into the reduction
             if (group == 0u) held = local;
             else if (group != 0xFFFFFFFFu && !(held.t <= local.t)) { held = local; closest_t = local.t; }
@@ -1013,9 +1101,22 @@ __device__ __forceinline__ Closest surface_again(WalkScene A, f3 o, f3 d, float 
             local_nested = false;
             bound = closest_t;
         }
-        if (pick < 0) break;
+        if (!any) break;
+        below = pick_rank;
+        if (MEDIA && medium >= 0) {
+            const uint32_t prim = S.media[medium];
+            uint4 hd;
+            Geom G;
+            load_prim(S, prim, hd, G);
+            if (!ref_reaches<true>(S, prim, 0u, o, d, t_min, bound)) continue;
+            const float t = medium_t(S, hd.x, G.g, o, d, time, t_min, bound, key);
+            if (!(t < local.t)) continue;
+            local.t = t; local.prim = prim; local.sx = ((hd.x >> 8) << 3) | ((hd.x & DP_TYPE_MASK) << 24); local.rank = hd.z;
+            local_nested = false;
+            bound = t;
+            continue;
+        }
         const Closest c = list[pick];
-        below = c.rank;
         const float4 b0 = S.prim_box[4u * c.prim], b1 = S.prim_box[4u * c.prim + 1u];
         const bool same_tree = local_nested && b0.x == local_b0.x && b0.y == local_b0.y && b0.z == local_b0.z && b0.w == local_b0.w &&
                                b1.x == local_b1.x && b1.y == local_b1.y;
@@ -1028,10 +1129,19 @@ __device__ __forceinline__ Closest surface_again(WalkScene A, f3 o, f3 d, float 
     }
     return held;
 }
-// `best` as the reference would have it: unchanged if the reference reaches that hit (or there is none)
-__device__ __forceinline__ void settle_surface(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_hi, Closest& best) {
-    if (best.t != INF && !hit_stands(S, best.prim, (best.sx >> 3) & 0x3FFFFFFu, o, d, t_min, t_hi, best.t))
-        best = surface_again(walk_scene(S), o, d, time, t_min, t_hi, best);
+// The closest hit of the whole scene as the reference has it, from `best`, the closest surface the walk of the device
+// tree found.  Short way, almost always: the surface stands (hit_stands) and the media go through the reference's
+// reduction with it (media_closest).  Otherwise the reference's sequence is played over the hits at the front.
+__device__ __forceinline__ void settle_hit(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_hi, const RngKey& key, Closest& best) {
+    if (best.t != INF && !hit_stands(S, best.prim, (best.sx >> 3) & 0x3FFFFFFu, o, d, t_min, t_hi, best.t)) {
+        if (S.n_media == 0u) best = front_sequence<false>(S, o, d, time, t_min, t_hi, best, key);
+        else best = front_sequence<true>(S, o, d, time, t_min, t_hi, best, key);
+        return;
+    }
+    if (S.n_media == 0u) return;
+    Closest with_media = best;
+    if (media_closest(S, o, d, time, t_min, t_hi, key, with_media)) best = with_media;
+    else best = front_sequence<true>(S, o, d, time, t_min, t_hi, best, key);
 }
 
 // closest hit of one ray per lane (used by the ray parity hook)
@@ -1049,10 +1159,7 @@ __device__ __forceinline__ void closest_hit(const DevScene& S, f3 o, f3 d, float
         else { if (wl) walker_leaf<COUNT>(W, S, cnt); }
     }
     best = W.best;
-    if (active) {
-        settle_surface(S, o, d, time, t_min, t_max, best);
-        media_closest(S, o, d, time, t_min, t_max, key, best);
-    }
+    if (active) settle_hit(S, o, d, time, t_min, t_max, key, best);
 }
 
 // ------------------------------------------------------------------ hit completion (only for the winner)
@@ -1640,19 +1747,27 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
 }
 
 // The slots that rt_shade_kernel put on hold: the closest surface rt_extend_kernel found for their ray does not stand
-// (hit_stands: the reference does not reach it, or it lies in front of its own box).  surface_again finds the hit the
+// (hit_stands: the reference does not reach it, or it lies in front of its own box).  settle_hit finds the hit the
 // reference ends up with; the hit record is marked settled, and the next rt_shade_kernel shades it.
 // Runs once per batch of bounces: a slot may wait a few launches, which changes nothing for its path.
 // sync[RT_REDO_COUNT]: number of entries in pool.redo, reset by the last workgroup to finish (sync[RT_REDO_COUNT + 1]
 // counts the finished ones).
-__global__ void __launch_bounds__(256) rt_redo_kernel(DevScene S, PathPool pool, uint32_t* __restrict__ sync) {
+__global__ void __launch_bounds__(256) rt_redo_kernel(DevScene S, RtRenderParams P, PathPool pool, uint32_t* __restrict__ sync) {
     const uint32_t n = __hip_atomic_load(sync + RT_REDO_COUNT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    // The slots are dealt to the waves first and to the lanes of a wave last: every slot takes its own way through the
+    // loops below, and the lanes of one wave would run those ways one after the other.
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    for (uint32_t i = (threadIdx.x & 63u) * n_waves + wave; i < n; i += 64u * n_waves) {
         const uint32_t slot = pool.redo[i];
         const float4 p0 = QP(pool, 0, slot), p1 = QP(pool, 1, slot), h = QP(pool, 3, slot);
+        const f3 o = mk3(p0.x, p0.y, p0.z), d = mk3(p1.x, p1.y, p1.z);
         Closest best;
         best.t = h.x; best.prim = __float_as_uint(h.y); best.sx = __float_as_uint(h.z); best.rank = __float_as_uint(h.w);
-        best = surface_again(walk_scene(S), mk3(p0.x, p0.y, p0.z), mk3(p1.x, p1.y, p1.z), p0.w, 0.001f, INF, best);
+        // the hit written back is the final one, media included
+        RngKey key;
+        path_key(P, (__float_as_uint(p1.w) >> DEPTH_COLUMN_SHIFT) & DEPTH_COLUMN_MASK, __float_as_uint(QP(pool, 2, slot).w), key);
+        key.bounce = (uint32_t)P.max_depth - (__float_as_uint(p1.w) & DEPTH_MASK);
+        settle_hit(S, o, d, p0.w, 0.001f, INF, key, best);
         QP(pool, 3, slot) = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(best.rank | RANK_SETTLED));
     }
     __syncthreads();
@@ -1703,23 +1818,26 @@ __global__ void __launch_bounds__(SHADE_BLOCK) rt_shade_kernel(DevScene S, RtCam
             best.t = q4.x; best.prim = __float_as_uint(q4.y); best.sx = __float_as_uint(q4.z);
             best.rank = __float_as_uint(q4.w) & ~RANK_SETTLED;
             const bool held = (__float_as_uint(q1.w) & DEPTH_HOLD) != 0u;
-            if (held && !(__float_as_uint(q4.w) & RANK_SETTLED)) {
-                q4.w = __uint_as_float(HIT_WAIT); // still waiting for rt_redo_kernel
-            } else if (!held && best.t != INF && !hit_stands(S, best.prim, (best.sx >> 3) & 0x3FFFFFFu, o, d, 0.001f, INF, best.t)) {
-                // plane 3 keeps {t, prim, sx, rank} of the hit that does not stand: where the redo starts from
+            bool hold = false, waiting = false;
+            if (held) {
+                // settled by rt_redo_kernel (its hit is the final one, media included), or still waiting for it
+                waiting = !(__float_as_uint(q4.w) & RANK_SETTLED);
+            } else if (best.t != INF && !hit_stands(S, best.prim, (best.sx >> 3) & 0x3FFFFFFu, o, d, 0.001f, INF, best.t)) {
+                hold = true;
+            } else if (S.n_media != 0u) {
+                RngKey key;
+                path_key(P, (__float_as_uint(q1.w) >> DEPTH_COLUMN_SHIFT) & DEPTH_COLUMN_MASK, __float_as_uint(q2.w), key);
+                key.bounce = (uint32_t)(P.max_depth - depth0);
+                hold = !media_closest(S, o, d, q0.w, 0.001f, INF, key, best); // (a medium hit in front of its own box)
+            }
+            if (hold) {
+                // plane 3 keeps {t, prim, sx, rank} of the closest surface of the device tree: where the redo starts from
                 reinterpret_cast<uint32_t*>(&QP(pool, 1, base + t))[3] = __float_as_uint(q1.w) | DEPTH_HOLD;
                 pool.redo[atomicAdd(sync + RT_REDO_COUNT, 1u)] = base + t;
-                q4.w = __uint_as_float(HIT_WAIT);
-            } else {
-                if (S.n_media != 0u) {
-                    RngKey key;
-                    path_key(P, (__float_as_uint(q1.w) >> DEPTH_COLUMN_SHIFT) & DEPTH_COLUMN_MASK, __float_as_uint(q2.w), key);
-                    key.bounce = (uint32_t)(P.max_depth - depth0);
-                    media_closest(S, o, d, q0.w, 0.001f, INF, key, best);
-                }
-                q4 = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx),
-                                 __uint_as_float(best.t != INF ? best.sx >> 29 : HIT_MISS));
             }
+            if (hold || waiting) q4.w = __uint_as_float(HIT_WAIT);
+            else q4 = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx),
+                                  __uint_as_float(best.t != INF ? best.sx >> 29 : HIT_MISS));
             hits[t] = q4;
             my_key = __float_as_uint(q4.w) & 7u;
         }
@@ -2018,8 +2136,7 @@ __global__ void __launch_bounds__(256) rt_trace_paths_kernel(DevScene S, RtCamer
             f3 no, nd;
             if (done) c = ps.color;
             else {
-                settle_surface(S, W.o, W.d, W.time, 0.001f, INF, W.best);
-                media_closest(S, W.o, W.d, W.time, 0.001f, INF, key, W.best);
+                settle_hit(S, W.o, W.d, W.time, 0.001f, INF, key, W.best);
                 done = shade<true>(S, W.o, W.d, W.time, W.best, ps, bgc, key, c, no, nd);
             }
             if (done) alive = false;
@@ -2055,8 +2172,8 @@ extern "C" void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, cons
                             d_radiance, d_sync, d_active);
     if (timing) (void)hipEventRecord(timing[2], stream);
 }
-extern "C" void rt_launch_redo(const DevScene* S, const PathPool* pool, uint32_t* d_sync, hipStream_t stream) {
-    hipLaunchKernelGGL(rt_redo_kernel, dim3(256), dim3(256), 0, stream, *S, *pool, d_sync);
+extern "C" void rt_launch_redo(const DevScene* S, const RtRenderParams* P, const PathPool* pool, uint32_t* d_sync, hipStream_t stream) {
+    hipLaunchKernelGGL(rt_redo_kernel, dim3(256), dim3(256), 0, stream, *S, *P, *pool, d_sync);
 }
 extern "C" void rt_launch_compact(const PathPool* from, float4* to, uint32_t* d_counts, uint32_t* d_sync, hipStream_t stream) {
     const uint32_t n_blocks = (from->n_slots + 255u) / 256u;

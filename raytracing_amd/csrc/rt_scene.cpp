@@ -510,6 +510,12 @@ struct Builder {
         std::sort(H.media.begin(), H.media.end(), [this](uint32_t a, uint32_t b) {
             return H.prims[3 * (size_t)a].z > H.prims[3 * (size_t)b].z; // rank: higher = met earlier by the reference
         });
+        for (uint32_t m : H.media) {
+            const uint32_t rank = H.prims[3 * (size_t)m].z;
+            uint32_t g = 0;
+            while (g + 1u < (uint32_t)D.n_buckets && rank < base[g]) ++g;
+            H.media_group.push_back(g);
+        }
         H.scene_reach = 0.0;
         for (const HostItem& it : H.items)
             for (int k = 0; k < 6; ++k)

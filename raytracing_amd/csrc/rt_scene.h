@@ -48,6 +48,7 @@ struct HostScene {
     std::vector<int32_t> perlin_perm;
     std::vector<int32_t> prim_top, prim_sub;
     std::vector<uint32_t> media; // the constant media (primitive indices) in descending rank
+    std::vector<uint32_t> media_group; // ... and the type group (position in the SceneManager tuple) of each
     std::vector<uint32_t> bucket_base; // lowest rank of every type group of the SceneManager, in its order (descending)
     uint32_t surface_root = 0, surface_size = 0, medium_root = 0, medium_size = 0; // layout-relative roots, node counts
 };
