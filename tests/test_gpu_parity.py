@@ -473,3 +473,100 @@ def test_converged_image_against_reference_gallery(name, key, spp, tol, scene_ca
     np.testing.assert_allclose((g ** 2).mean(axis=(0, 1)), stats["linear_mean"], atol=0.004)
     row = g[g.shape[0] // 2].sum(axis=1)
     assert abs(int(np.argmax(row > 0.02)) - stats["black_frame_px"]) <= 1
+
+
+GALLERY = {   # scene -> (key in gallery_blocks.npz, spp of that picture, spp of the three renders that decide the mask,
+              #           spread limit, RMSE bound, bias bound, least mask share)
+    "cover1": ("cover1_500", 500, 500, 0.01, 0.004, 0.002, 0.25),
+    "cu_cover2": ("cu_cover2_1000", 1000, 1000, 0.02, 0.012, 0.004, 0.50),
+    "cover2": ("cover2_100", 100, 100, 0.03, 0.030, 0.004, 0.40),
+}
+
+
+def _erode(m):
+    e = m.copy()
+    e[1:, :] &= m[:-1, :]; e[:-1, :] &= m[1:, :]; e[:, 1:] &= m[:, :-1]; e[:, :-1] &= m[:, 1:]
+    return e
+
+
+@pytest.mark.parametrize("name", list(GALLERY))
+def test_deterministic_regions_against_reference_gallery(name):
+    """The reference's pictures of the scenes it builds with the unseeded rand() (outputs/cover1_500_samples.png,
+    cu_cover2_1000_samples.png, cover2_100_samples.png; 8x8 block means in tests/golden/gallery_blocks.npz) pin whatever in
+    them does not depend on the random part of the scene: the sky, the three large spheres of cover1 (Dielectric, Lambertian,
+    Metal with fuzz 0); the light, the fog, the moving sphere, the glass, metal and blue-medium spheres of cu_cover2; the
+    earth sphere of cover2 (ImageTexture + get_sphere_uv).  Which blocks those are is decided by rendering the scene with
+    three scene seeds: a block takes part if the three renders agree within the spread limit there and in its four
+    neighbours.  On those blocks the mean of the three renders, made at the picture's own sample count (equal counts: the
+    sqrt of a noisy mean is biased and bright pixels are clamped, equally on both sides), must equal the reference's picture:
+    per-channel RMSE and bias below the stated bounds (gamma space), the worst 1 % of blocks left out (blocks where the
+    reference's own random spheres show and none of ours do).  Stated bounds: cover1 0.004 (measured 0.001), cu_cover2
+    0.012 (0.008: the noise of a 1000-spp picture), cover2 at 100 spp 0.03 (0.02).
+    Two things in the reference's gallery do not fit the rest of it and are left out.  outputs/cover2_10000_samples.png is
+    brighter than outputs/cover2_100_samples.png by 14 % (fog) to 42 % (moving sphere) in linear radiance, which no sample
+    count explains (means of linear radiance do not depend on it; this library gives the same means at 100, 1000 and 10 000
+    spp, and they are those of the 100-sample picture and of the CUDA picture cu_cover2_1000): it must come from another
+    revision of the scene or the code.  And the fuzzy metal sphere of cover2_100 is evenly grey where the reference's two
+    other pictures of that sphere (and this library) show a highlight and a dark side, so that one object is not compared
+    in cover2 (it is in cu_cover2)."""
+    from raytracing_amd.hittables import ConstantMedium
+    key, spp, mask_spp, spread_limit, tol, bias_tol, least = GALLERY[name]
+    G = np.load(os.path.join(HERE, "golden", "gallery_blocks.npz"))
+    want, B = G[key].astype(np.float64), int(G["block"])
+
+    def blocks_of(seed, n):
+        world, kw = rt.get_scene(name, spp=n, seed=seed)
+        dev = rt.DeviceScene(world)
+        try:
+            img, st = dev.render(kw["camera"], kw["pattern"], kw["background"], kw["width"], kw["height"])
+        finally:
+            dev.close()
+        g = np.round(np.clip(np.nan_to_num(img), 0, 1).astype(np.float64) * 255) / 255
+        h, w, _ = g.shape
+        return g.reshape(h // B, B, w // B, B, 3).mean(axis=(1, 3)), world, kw
+
+    renders = []
+    for seed in (1, 2, 3):
+        blocks, world, kw = blocks_of(seed, mask_spp)
+        renders.append(blocks)
+        if seed == 1:
+            # which object a block shows (primary ray through its centre, constant media left out: their hits are random)
+            solid = [o for o in world if not isinstance(o, ConstantMedium)]
+            probe = rt.DeviceScene(solid)
+            try:
+                h, w = kw["height"], kw["width"]
+                hit = probe.trace_rays(O.primary_rays(kw["camera"], w, h, w // B, h // B, time=0.5))["prim_id"].reshape(h // B, w // B)[::-1]
+            finally:                              # (rows of rays count from the bottom)
+                probe.close()
+    assert renders[0].shape == want.shape
+    spread = np.max([np.abs(renders[i] - renders[j]).max(axis=2) for i in range(3) for j in range(i)], axis=0)
+    mask = _erode(spread < spread_limit)
+    assert mask.mean() > least, mask.mean()
+    mean = sum(renders) / 3 if spp == mask_spp else blocks_of(1, spp)[0]   # (every entry of GALLERY has equal counts today)
+    d = (mean - want)[mask]
+    worst = np.abs(d).max(axis=1)
+    d = d[worst <= np.quantile(worst, 0.99)]
+    rmse, bias = np.sqrt((d ** 2).mean(axis=0)), d.mean(axis=0)
+    # the named objects one by one: enough of each must be among the blocks compared, and agree
+    if name == "cover1":
+        named = {"sky": -1, "glass sphere": len(solid) - 3, "lambertian sphere": len(solid) - 2, "metal sphere": len(solid) - 1}
+    else:
+        named = {"light": 0, "moving sphere": 1, "glass sphere": 2, "metal sphere": 3, "sphere of the blue medium": 4, "fog": -1}
+        named["earth sphere" if name == "cover2" else "placeholder sphere"] = 5
+        if name == "cover2":
+            del named["metal sphere"]
+    report = {}
+    for label, pid in named.items():
+        sel = mask & (hit == pid)
+        dd = (mean - want)[sel]
+        if len(dd) > 20:
+            w_ = np.abs(dd).max(axis=1)
+            dd = dd[w_ <= np.quantile(w_, 0.98)]
+        report[label] = (int(sel.sum()), float(np.sqrt((dd ** 2).mean())) if len(dd) else float("nan"))
+        if os.environ.get("RT_AMD_GALLERY_VERBOSE") and len(dd):
+            print("   ", label, "blocks", int(sel.sum()), "bias", dd.mean(axis=0).round(4), "level", want[sel].mean(axis=0).round(3))
+    print(name, "rmse", rmse.round(4), "bias", bias.round(4), "mask", round(float(mask.mean()), 3), report)
+    assert (rmse < tol).all() and (np.abs(bias) < bias_tol).all(), (rmse, bias)
+    for label, (count, r) in report.items():
+        assert count >= 12, (label, count)
+        assert r < 2.0 * tol, (label, r)
