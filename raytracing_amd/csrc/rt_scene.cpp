@@ -648,7 +648,54 @@ void rt_build_nodes(HostScene* out, double reach) {
             radius = std::min(radius, valid[k] - std::sqrt(d2));
         }
     }
-    const bool two_sets = n_tight != 0 && radius > 0.0 && std::isfinite(radius);
+    // Spheres that are not tightened limit the ball as well: their leaves must grow to hold every point the sphere test can
+    // report (below), by sqrt(r^2 + 1.4e-6 D^2) - r for rays that have come at most D, and the ball is kept small enough
+    // for that to stay within a tenth of the radius (1.4e-6 D^2 <= 0.21 r^2: D <= 387 r).  A scene of small spheres on a
+    // huge one (the ground of samples/cover_in_one_weekend.jl is a sphere of radius 1000 around 488 of radius 0.2) would
+    // otherwise carry boxes twenty radii wide for the sake of rays that start at its far end.
+    auto world_radius = [&H](uint32_t prim) { // radius of a sphere primitive as the world sees it, at least; 0: not a sphere
+        const uint4 h = H.prims[3 * (size_t)prim], g1 = H.prims[3 * (size_t)prim + 1], g2 = H.prims[3 * (size_t)prim + 2];
+        const uint32_t kind = h.x & 15u;
+        double r = 0.0;
+        if (kind == DP_SPHERE) r = std::fabs((double)bitsf(g1.z));
+        if (kind == DP_MOVING_SPHERE) r = std::fabs((double)bitsf(g2.w));
+        if ((kind == DP_SPHERE || kind == DP_MOVING_SPHERE) && (h.x >> 8) != 0u) {
+            const float* M = &H.xforms[24 * (size_t)((h.x >> 8) - 1u)];
+            double shrink = INFINITY;
+            for (int i = 0; i < 3; ++i) shrink = std::min(shrink, std::sqrt((double)M[i] * M[i] + (double)M[3 + i] * M[3 + i] + (double)M[6 + i] * M[6 + i]));
+            r *= std::min(1.0, shrink);
+        }
+        return std::isfinite(r) ? r : 0.0;
+    };
+    // How far a leaf can be from a point of the ball, beyond the ball's radius.  The box of a leaf inside a nested tree is in
+    // that tree's own frame: its place in the world is only known to lie within the scene.
+    auto offset_from_centre = [&](size_t k) {
+        double off = 0.0, c2 = 0.0;
+        for (int i = 0; i < 3; ++i) {
+            const double a = std::max(std::fabs((double)loose[k].b[i] - H.centre[i]), std::fabs((double)loose[k].b[3 + i] - H.centre[i]));
+            if (std::isfinite(a)) off += a * a;
+            c2 += (double)H.centre[i] * H.centre[i];
+        }
+        return H.items[k].tree >= 2u ? std::sqrt(c2) + std::sqrt(3.0) * H.scene_reach : std::sqrt(off);
+    };
+    {
+        std::vector<size_t> plain; // surface leaves that hold a sphere and keep the reference's box
+        for (size_t k = 0; k < n; ++k)
+            if (H.items[k].tree != 1u && valid[k] == INFINITY && world_radius((H.items[k].leaf & RT_LEAF_PRIM_MASK) - 1u) > 0.0) plain.push_back(k);
+        if (!plain.empty()) {
+            if (!n_tight) { // no tightened primitive to centre the ball on: the median of those spheres, axis by axis
+                for (int i = 0; i < 3; ++i) {
+                    std::vector<double> c;
+                    for (size_t k : plain) c.push_back(0.5 * ((double)loose[k].b[i] + (double)loose[k].b[3 + i]));
+                    std::nth_element(c.begin(), c.begin() + c.size() / 2, c.end());
+                    H.centre[i] = std::isfinite(c[c.size() / 2]) ? (float)c[c.size() / 2] : 0.0f;
+                }
+            }
+            for (size_t k : plain)
+                radius = std::min(radius, 387.0 * world_radius((H.items[k].leaf & RT_LEAF_PRIM_MASK) - 1u) - offset_from_centre(k));
+        }
+    }
+    const bool two_sets = radius > 0.0 && std::isfinite(radius);
     H.n_sets = two_sets ? 2u : 1u;
     H.radius = two_sets ? (float)(radius * 0.999) : INFINITY;
     // The walk drops a box that begins behind the closest hit so far, so a box must hold every point at which its
@@ -680,16 +727,14 @@ void rt_build_nodes(HostScene* out, double reach) {
                 b[3 + i] = std::nextafter((float)((double)b[3 + i] + e), INFINITY);
             }
         };
-        double far_c = 0.0, off_c = 0.0; // farthest corner of the box from the origin / from the ball's centre
+        double far_c = 0.0; // farthest corner of the box from the origin
         for (int i = 0; i < 3; ++i) {
             const double a0 = std::max(std::fabs((double)loose[k].b[i]), std::fabs((double)loose[k].b[3 + i]));
-            const double a1 = std::max(std::fabs((double)loose[k].b[i] - H.centre[i]), std::fabs((double)loose[k].b[3 + i] - H.centre[i]));
             if (std::isfinite(a0)) far_c += a0 * a0;
-            if (std::isfinite(a1)) off_c += a1 * a1;
         }
         const bool tightened = valid[k] != INFINITY;
         grow(loose[k].b, std::sqrt(3.0) * reach + std::sqrt(far_c) + (H.items[k].tree >= 2u ? H.scene_reach : 0.0)); // nested: box in the tree's own frame
-        if (two_sets && !tightened) grow(tight[k].b, (double)H.radius + std::sqrt(off_c));
+        if (two_sets && !tightened) grow(tight[k].b, (double)H.radius + offset_from_centre(k));
     }
     if (!two_sets) tight = loose; // no ball in which every tight box is valid: one set of loose boxes
     const uint32_t n_trees = (uint32_t)H.tree_first.size();

@@ -275,5 +275,6 @@ def test_nested_tree_inlined_or_kept(monkeypatch):
     assert info2.surface_size < info.surface_size
     assert sorted(set(prim_top)) == sorted(set(prim_top2))
     # rotated spheres: tight boxes in the first set, valid inside a ball around them; the nested tree itself is walked in
-    # its own frame, where a sphere's box is the reference's: nothing to tighten, one set
+    # its own frame, where a sphere's box is the reference's and its place in the world is only known to lie within the
+    # scene: no ball in which its small spheres' leaves could stay small, one set
     assert info.n_sets == 2 and 0 < info.radius < 1e5 and info2.n_sets == 1

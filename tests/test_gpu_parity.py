@@ -180,6 +180,19 @@ def test_uneven_columns_drain_every_path_dispenser(width, height, monkeypatch):
         dev.close()
 
 
+@pytest.mark.parametrize("name", SCENES)
+def test_walk_statistics_stay_small(name, scenes):
+    """The device tree's quality, counted, not timed: node tests and primitive tests per ray of the counting build.  A
+    tree whose leaves overlap everything still gives the right pictures, only ten times slower (sphere leaves grown for
+    rays from the far end of the huge ground sphere of cover1 once did that: 309 node tests and 122 primitive tests per
+    ray).  Measured: 9 .. 24 node tests and 1.3 .. 1.8 primitive tests per ray."""
+    world, kw, dev, ref = scenes(name)
+    W, H = kw["width"] // 4, kw["height"] // 4
+    _, st = dev.render(kw["camera"], kw["pattern"][:, :4], kw["background"], W, H, flags=ffi.RT_FLAG_COUNTERS)
+    assert st.rays >= st.paths == W * H * 4
+    assert st.node_visits / st.rays < 40 and st.prim_tests / st.rays < 4, (st.node_visits / st.rays, st.prim_tests / st.rays)
+
+
 def test_errors_on_device(scenes):
     world, kw, dev, ref = scenes("cornell_box")
     L = ffi.lib()
