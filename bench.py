@@ -53,8 +53,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scene", default="cu_cover2")
     ap.add_argument("--spp", type=int, default=1000)
-    ap.add_argument("--cpu-spp", type=int, default=64, help="pattern columns of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=24, help="pattern columns of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-other", action="store_true", help="skip the other BASELINE configurations (one frame each)")
     args = ap.parse_args()
 
     import numpy as np
@@ -83,16 +84,14 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
+    from raytracing_amd.distributed import sharded_frame
+
     def step(k=None):
         if k is not None:
             ev0[k].record()
-        scene.accumulate(cam, pattern, bg, W, H, accum.data_ptr(), sample_first=rank, sample_stride=world_size,
-                         stream=stream)
-        if k is not None:
-            ev1[k].record()
-        if world_size > 1:
-            dist.all_reduce(accum)
-        scene.finalize(accum.data_ptr(), n, W, H, out.data_ptr(), stream=stream)
+        sharded_frame(scene, cam, pattern, bg, W, H, accum, out, rank, world_size,
+                      all_reduce=dist.all_reduce if world_size > 1 else None, stream=stream,
+                      after_accumulate=(lambda: ev1[k].record()) if k is not None else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -133,15 +132,22 @@ def main():
             # reference algorithm, which define the algorithmic flops/bytes per path used for the roofline.
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_ffi as O
-            cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+            # threads: the CPU share of this job (OMP_NUM_THREADS where the harness sets it -- 16 per GPU on the boxes
+            # this runs on, although os.cpu_count() shows the whole machine), else every core the host has
+            cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
             ref = O.OracleScene(world)
             # (with more than one GPU the CPU baseline is not reported; a few columns then give the event counts)
             cpu_cols = args.cpu_spp if world_size == 1 else min(4, args.cpu_spp)
             cpu_pat = rt.Halton_sequence32(cpu_cols)
-            _, st = ref.render(cam, cpu_pat, bg, W, H, threads=cores, stats=True)
+            runs = []
+            for _ in range(3 if world_size == 1 else 1):
+                _, st = ref.render(cam, cpu_pat, bg, W, H, threads=cores, stats=True)
+                runs.append(st.paths / st.seconds / 1e6)
             if world_size == 1:
-                cpu = {"value": st.paths / st.seconds / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
-                       "sample": "%s %dx%d, %d of %d pattern columns (%.1f s)" % (args.scene, W, H, cpu_cols, n, st.seconds)}
+                cpu = {"value": max(runs), "unit": "Mpaths/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
+                       "runs": [round(r, 3) for r in runs],
+                       "sample": "%s %dx%d, %d of %d pattern columns, best of %d runs (%.1f s each)" % (
+                           args.scene, W, H, cpu_cols, n, len(runs), st.seconds)}
             flops_pp, bytes_pp, events = algorithmic_work(st)
             # Dominant kernel = rt_extend_kernel (BVH traversal + intersection).  Its launches of one extra frame are
             # bracketed with HIP events on the launch stream (RT_FLAG_TIMING); algorithmic work per launch = the
@@ -164,18 +170,39 @@ def main():
                         "flops_per_path": trav, "bytes_per_path": trav_b, "flops_per_path_incl_shading": flops_pp,
                         "node_fetch_GBps": trav_b * paths_per_launch / avg_s / 1e9,
                         "events_per_path": {k: round(v, 3) for k, v in events.items()}}
+            # HBM bytes per launch and the VALU readings come from PMC passes (rocprofv3 --pmc, run apart from the timed
+            # run as the counters need); the committed summary of the latest passes is read here and named as the source
             pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(pmc):
                 with open(pmc) as f:
                     prof = json.load(f)
                 roofline["traffic"] = prof.get(args.scene)
-                # from the same committed profile (PMC passes over one frame): how busy the vector ALUs were and how many
-                # of the 64 lanes of an instruction did work -- the hardware-side reading of a VALU-bound kernel
+                roofline["traffic_source"] = "profiles/hbm_traffic.json (%s): not measured by this run" % prof.get(args.scene + "_profile", "PMC passes")
                 if args.scene + "_valu_busy" in prof:
                     roofline["valu_busy_profiled"] = prof[args.scene + "_valu_busy"]
                     roofline["lanes_active_profiled"] = prof[args.scene + "_lanes_active"]
         line["roofline"] = roofline
         line["cpu_baseline"] = cpu
+        if world_size == 1 and not args.no_other and args.scene == "cu_cover2":
+            # the other configurations BASELINE.json names, one GPU each, second frame of a resident scene (buffers warm)
+            other = {}
+            for key, spp in (("cover1", 500), ("teapot", 1000), ("cornell_box", 1000), ("cornell_smoke_box", 10000)):
+                w2, k2 = rt.get_scene(key, spp=spp)
+                sc2 = rt.DeviceScene(w2, device=local_rank)
+                a2 = (k2["camera"], k2["pattern"], k2["background"], k2["width"], k2["height"])
+                acc2 = torch.zeros(3 * k2["width"] * k2["height"], dtype=torch.float32, device=dev)
+                best = None
+                for _ in range(2):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    sharded_frame(sc2, *a2, acc2, acc2, 0, 1, stream=stream)
+                    torch.cuda.synchronize()
+                    best = time.perf_counter() - t1
+                paths = k2["width"] * k2["height"] * spp
+                other["%s %d spp" % (key, spp)] = {"Mpaths_per_s": paths / best / 1e6, "s_per_frame": best, "paths": paths,
+                                                  "size": "%dx%d" % (k2["width"], k2["height"])}
+                sc2.close()
+            line["other_configs"] = other
         print(json.dumps(line), flush=True)
     scene.close()
     if world_size > 1:
