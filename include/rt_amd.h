@@ -35,7 +35,8 @@ typedef enum rtStatus {
     RT_ENODEV = -2,
     RT_ENOMEM = -3,
     RT_EHIP = -4,
-    RT_EUNSUPPORTED = -5
+    RT_EUNSUPPORTED = -5,
+    RT_ERCCL = -6
 } rtStatus;
 
 /* object kinds: one per concrete Hittable of the reference */
@@ -178,6 +179,22 @@ int rt_scene_destroy(rtScene* scene);
 int rt_render(rtScene* scene, const rtCamera* camera, const float* pattern /* 2 x n column-major, host */, int n,
               const float background[3], int width, int height, int max_depth, uint64_t seed, uint32_t flags,
               float* out, rtStats* stats);
+
+/* One host process, several GPUs.  The reference's render(...; gpu=true) is one process on one device (main.jl:34-38,
+ * src/Ray_Tracing.jl:141-157); a group is what lets that one call use every GPU of a node: the scene is copied to each
+ * device of the list (n_devices = 0: every visible device), rt_group_render deals the pattern columns to them (member g
+ * of G traces columns g, g + G, ...; one host thread per member), sums the members' FP32 accumulators on the first device
+ * -- with RCCL (ncclReduce over xGMI; librccl.so.1 is loaded when a group of more than one device first renders, and
+ * RT_ERCCL reports its absence or failure), or with peer copies and adds in member order when the environment says
+ * RT_AMD_REDUCE=peer or the list names a device twice (several shards on one GPU, for tests) -- finalises there and
+ * copies the image to `out` like rt_render.  A group of one device renders exactly what rt_render renders, bit for bit;
+ * with more members only the order of the FP32 sums differs.  Blocking; a group is not re-entrant. */
+typedef struct rtGroup rtGroup;
+int rt_group_create(const rtSceneDesc* desc, const int* devices, int n_devices, rtGroup** out);
+int rt_group_size(const rtGroup* group, int* n_devices);
+int rt_group_render(rtGroup* group, const rtCamera* camera, const float* pattern, int n, const float background[3],
+                    int width, int height, int max_depth, uint64_t seed, uint32_t flags, float* out, rtStats* stats);
+int rt_group_destroy(rtGroup* group);
 
 /* The two halves of rt_render for spp sharding across GPUs (one process per GPU):
  * rt_render_accumulate replaces the @cuda draw_kernel launch (src/Ray_Tracing.jl:151): it WRITES to the device

@@ -9,5 +9,5 @@ from .hittables import (AABB, Box, Camera, CheckerTexture, ConstantMedium, Diele
                         ImageTexture, Isotropic, Lambertian, Material, Mesh, Metal, MovingSphere, NoiseTexture,
                         RotY, SolidColor, Sphere, Transform, Vec3, affine, bounding_box, xy_rect, xz_rect, yz_rect)
 from .scene_manager import BVHTree, SceneManager, build_bvh, build_bvh_scene, type_key
-from .render import DeviceScene, render, save, save_scene, clamp01, to_rgb8
+from .render import DeviceGroup, DeviceScene, render, save, save_scene, clamp01, to_rgb8
 from .scenes import get_scene, scenes, scenes_list

@@ -1,0 +1,244 @@
+// rt_group.cpp -- one host process driving several GPUs: the scene replicated per device, the pattern columns dealt to
+// the devices (device g of G traces columns g, g + G, ...), one host thread per device, the per-device accumulators summed
+// on the first device -- by RCCL (ncclReduce over xGMI; librccl is loaded when the first multi-device group needs it) or,
+// on request, by peer copies and an add kernel in device order -- then finalised and copied out.  The reference renders
+// on one device from one process (main.jl:34-38); this is what lets that one call use every GPU of a node.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "rt_internal.h"
+#include "rt_kernels.h"
+
+namespace {
+
+// the few RCCL entry points the reduction needs, bound at run time
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+
+const Rccl* rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.lib || !g_rccl.error.empty()) return &g_rccl;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* name : names) {
+        g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) {
+        g_rccl.error = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "unknown error");
+        return &g_rccl;
+    }
+    bool ok = true;
+    auto bind = [&ok](void* lib, const char* sym) { void* p = dlsym(lib, sym); if (!p) ok = false; return p; };
+    g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))bind(g_rccl.lib, "ncclCommInitAll");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))bind(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))bind(g_rccl.lib, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))bind(g_rccl.lib, "ncclGroupEnd");
+    g_rccl.Reduce = (decltype(g_rccl.Reduce))bind(g_rccl.lib, "ncclReduce");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))bind(g_rccl.lib, "ncclGetErrorString");
+    if (!ok) {
+        g_rccl.error = "librccl.so.1 lacks an entry point the reduction needs";
+        dlclose(g_rccl.lib);
+        g_rccl.lib = nullptr;
+    }
+    return &g_rccl;
+}
+
+} // namespace
+
+struct rtGroup {
+    std::vector<int> devices;
+    std::vector<rtScene*> scenes;
+    std::vector<hipStream_t> streams;
+    std::vector<float*> accum;        // per member: 3 * H * W floats on its device
+    std::vector<size_t> accum_cap;
+    float* stage = nullptr;           // on the first device: where a peer's accumulator lands before it is added
+    size_t stage_cap = 0;
+    std::vector<ncclComm_t> comms;    // one per member once the group has reduced over RCCL
+    bool distinct = true;             // no device appears twice (RCCL needs that)
+};
+
+#define GROUP_HIP(expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return rt_fail(e_ == hipErrorOutOfMemory ? RT_ENOMEM : RT_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" {
+
+int rt_group_destroy(rtGroup* g) {
+    if (!g) return RT_OK;
+    const Rccl* R = g->comms.empty() ? nullptr : rccl();
+    for (size_t k = 0; k < g->devices.size(); ++k) {
+        (void)hipSetDevice(g->devices[k]);
+        if (k < g->comms.size() && g->comms[k] && R && R->CommDestroy) (void)R->CommDestroy(g->comms[k]);
+        if (k < g->accum.size() && g->accum[k]) (void)hipFree(g->accum[k]);
+        if (k < g->streams.size() && g->streams[k]) (void)hipStreamDestroy(g->streams[k]);
+        if (k < g->scenes.size() && g->scenes[k]) (void)rt_scene_destroy(g->scenes[k]);
+    }
+    if (g->stage) { (void)hipSetDevice(g->devices[0]); (void)hipFree(g->stage); }
+    delete g;
+    return RT_OK;
+}
+
+int rt_group_create(const rtSceneDesc* desc, const int* devices, int n_devices, rtGroup** out) {
+    if (!desc || !out) return rt_fail(RT_EINVAL, "rt_group_create: null argument");
+    *out = nullptr;
+    if (n_devices < 0 || (n_devices > 0 && !devices)) return rt_fail(RT_EINVAL, "rt_group_create: bad device list");
+    int visible = 0;
+    hipError_t e = hipGetDeviceCount(&visible);
+    if (e != hipSuccess || visible == 0) return rt_fail(RT_ENODEV, "no HIP device available (%s)", hipGetErrorString(e));
+    rtGroup* g = new (std::nothrow) rtGroup();
+    if (!g) return rt_fail(RT_ENOMEM, "out of host memory");
+    if (n_devices == 0) for (int d = 0; d < visible; ++d) g->devices.push_back(d);
+    else g->devices.assign(devices, devices + n_devices);
+    for (size_t a = 0; a < g->devices.size(); ++a) {
+        if (g->devices[a] < 0 || g->devices[a] >= visible) {
+            const int bad = g->devices[a];
+            delete g;
+            return rt_fail(RT_EINVAL, "device %d out of range (0..%d)", bad, visible - 1);
+        }
+        for (size_t b = 0; b < a; ++b) if (g->devices[a] == g->devices[b]) g->distinct = false;
+    }
+    const size_t G = g->devices.size();
+    g->scenes.assign(G, nullptr);
+    g->streams.assign(G, nullptr);
+    g->accum.assign(G, nullptr);
+    g->accum_cap.assign(G, 0);
+    for (size_t k = 0; k < G; ++k) {
+        int st = rt_scene_create(desc, g->devices[k], &g->scenes[k]); // (leaves that device current)
+        if (st == RT_OK && hipStreamCreateWithFlags(&g->streams[k], hipStreamNonBlocking) != hipSuccess)
+            st = rt_fail(RT_EHIP, "hipStreamCreate failed on device %d", g->devices[k]);
+        if (st != RT_OK) {
+            const std::string msg = rt_last_error();
+            rt_group_destroy(g);
+            return rt_fail(st, "%s", msg.c_str());
+        }
+    }
+    *out = g;
+    return RT_OK;
+}
+
+int rt_group_size(const rtGroup* g, int* n_devices) {
+    if (!g || !n_devices) return rt_fail(RT_EINVAL, "rt_group_size: null argument");
+    *n_devices = (int)g->devices.size();
+    return RT_OK;
+}
+
+int rt_group_render(rtGroup* g, const rtCamera* camera, const float* pattern, int n, const float background[3], int width,
+                    int height, int max_depth, uint64_t seed, uint32_t flags, float* out, rtStats* stats) {
+    if (!g || !camera || !pattern || !background || !out) return rt_fail(RT_EINVAL, "rt_group_render: null argument");
+    if (width < 2 || height < 2) return rt_fail(RT_EINVAL, "width and height must be at least 2");
+    if ((uint64_t)width * (uint64_t)height > 0x7FFFFFFFull / 3ull) return rt_fail(RT_EINVAL, "image too large");
+    if (flags & RT_FLAG_COUNTERS) return rt_fail(RT_EINVAL, "rt_group_render: RT_FLAG_COUNTERS is per scene (use rt_render)");
+    const size_t G = g->devices.size();
+    const size_t image_floats = (size_t)3 * (size_t)width * (size_t)height;
+    for (size_t k = 0; k < G; ++k) {
+        if (g->accum_cap[k] >= image_floats) continue;
+        GROUP_HIP(hipSetDevice(g->devices[k]));
+        if (g->accum[k]) { GROUP_HIP(hipFree(g->accum[k])); g->accum[k] = nullptr; g->accum_cap[k] = 0; }
+        GROUP_HIP(hipMalloc((void**)&g->accum[k], image_floats * sizeof(float)));
+        g->accum_cap[k] = image_floats;
+    }
+    GROUP_HIP(hipSetDevice(g->devices[0]));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct EventGuard {
+        hipEvent_t &a, &b;
+        ~EventGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } guard{e0, e1};
+    GROUP_HIP(hipEventCreate(&e0));
+    GROUP_HIP(hipEventCreate(&e1));
+    GROUP_HIP(hipEventRecord(e0, g->streams[0]));
+    // one host thread per member: its share of the pattern columns into its own accumulator
+    std::vector<int> status(G, RT_OK);
+    std::vector<std::string> message(G);
+    auto work = [&](size_t k) {
+        int st = rt_render_accumulate(g->scenes[k], camera, pattern, n, (int)k, (int)G, background, width, height, max_depth, seed,
+                                      flags & ~RT_FLAG_TIMING, g->accum[k], g->streams[k]);
+        if (st == RT_OK && hipStreamSynchronize(g->streams[k]) != hipSuccess) st = rt_fail(RT_EHIP, "hipStreamSynchronize failed");
+        status[k] = st;
+        if (st != RT_OK) message[k] = rt_last_error(); // (the message lives in this thread)
+    };
+    if (G == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> threads;
+        for (size_t k = 0; k < G; ++k) threads.emplace_back(work, k);
+        for (std::thread& t : threads) t.join();
+    }
+    for (size_t k = 0; k < G; ++k)
+        if (status[k] != RT_OK) return rt_fail(status[k], "device %d (member %zu of %zu): %s", g->devices[k], k, G, message[k].c_str());
+    // the sum of the members' accumulators, on the first device
+    const char* how = std::getenv("RT_AMD_REDUCE"); // "peer": copies and adds in member order instead of RCCL
+    const bool peer = (how && std::strcmp(how, "peer") == 0) || !g->distinct;
+    if (G > 1 && peer) {
+        GROUP_HIP(hipSetDevice(g->devices[0]));
+        if (g->stage_cap < image_floats) {
+            if (g->stage) { GROUP_HIP(hipFree(g->stage)); g->stage = nullptr; g->stage_cap = 0; }
+            GROUP_HIP(hipMalloc((void**)&g->stage, image_floats * sizeof(float)));
+            g->stage_cap = image_floats;
+        }
+        for (size_t k = 1; k < G; ++k) {
+            GROUP_HIP(hipMemcpyPeerAsync(g->stage, g->devices[0], g->accum[k], g->devices[k], image_floats * sizeof(float), g->streams[0]));
+            rt_launch_add(g->accum[0], g->stage, image_floats, g->streams[0]);
+            GROUP_HIP(hipGetLastError());
+        }
+    } else if (G > 1 || std::getenv("RT_AMD_FORCE_RCCL")) {
+        const Rccl* R = rccl();
+        if (!R->lib) return rt_fail(RT_ERCCL, "%s (RT_AMD_REDUCE=peer sums with peer copies instead)", R->error.c_str());
+        if (g->comms.empty()) {
+            g->comms.assign(G, nullptr);
+            ncclResult_t r = R->CommInitAll(g->comms.data(), (int)G, g->devices.data());
+            if (r != ncclSuccess) { g->comms.clear(); return rt_fail(RT_ERCCL, "ncclCommInitAll failed: %s", R->GetErrorString(r)); }
+        }
+        ncclResult_t r = R->GroupStart();
+        hipError_t he = hipSuccess;
+        for (size_t k = 0; k < G && r == ncclSuccess && he == hipSuccess; ++k) {
+            he = hipSetDevice(g->devices[k]);
+            if (he == hipSuccess) r = R->Reduce(g->accum[k], g->accum[k], image_floats, ncclFloat, ncclSum, 0, g->comms[k], g->streams[k]);
+        }
+        ncclResult_t r2 = R->GroupEnd(); // (always closed, whatever happened inside)
+        if (r == ncclSuccess) r = r2;
+        if (he != hipSuccess) return rt_fail(RT_EHIP, "hipSetDevice failed: %s", hipGetErrorString(he));
+        if (r != ncclSuccess) return rt_fail(RT_ERCCL, "ncclReduce failed: %s", R->GetErrorString(r));
+        for (size_t k = 1; k < G; ++k) { GROUP_HIP(hipSetDevice(g->devices[k])); GROUP_HIP(hipStreamSynchronize(g->streams[k])); }
+    }
+    GROUP_HIP(hipSetDevice(g->devices[0]));
+    int st = rt_finalize(g->scenes[0], g->accum[0], n, width, height, g->accum[0], g->streams[0]);
+    if (st != RT_OK) return st;
+    GROUP_HIP(hipEventRecord(e1, g->streams[0]));
+    GROUP_HIP(hipMemcpyAsync(out, g->accum[0], image_floats * sizeof(float), hipMemcpyDeviceToHost, g->streams[0]));
+    GROUP_HIP(hipStreamSynchronize(g->streams[0]));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        float ms = 0.0f;
+        GROUP_HIP(hipEventElapsedTime(&ms, e0, e1));
+        stats->seconds = (double)ms * 1e-3; // first device's clock: from its first kernel to the finalised image
+        stats->paths = (uint64_t)width * (uint64_t)height * (uint64_t)n;
+    }
+    return RT_OK;
+}
+
+} // extern "C"

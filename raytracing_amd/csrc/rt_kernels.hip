@@ -2045,6 +2045,12 @@ __global__ void __launch_bounds__(256) rt_sum_kernel(RtRenderParams P, const flo
     accum[idx] = col.x; accum[idx + 1] = col.y; accum[idx + 2] = col.z;
 }
 
+// dst += src (the accumulator of another GPU, copied over, into the first one's)
+__global__ void __launch_bounds__(256) rt_add_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = dst[i] + src[i];
+}
+
 // col /= N; sqrt per channel (src/Ray_Tracing.jl:90-91,152-153; the division is a multiply by Float32(1/N))
 __global__ void __launch_bounds__(256) rt_finalize_kernel(const float* __restrict__ accum, float inv_n,
                                                           size_t image_floats, float* __restrict__ out) {
@@ -2183,6 +2189,9 @@ extern "C" void rt_launch_compact(const PathPool* from, float4* to, uint32_t* d_
 }
 extern "C" void rt_launch_sum(const RtRenderParams* P, const float4* d_radiance, float* d_accum, int first_batch, hipStream_t stream) {
     hipLaunchKernelGGL(rt_sum_kernel, dim3((P->n_pixels + 255u) / 256u), dim3(256), 0, stream, *P, d_radiance, d_accum, first_batch);
+}
+extern "C" void rt_launch_add(float* d_dst, const float* d_src, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(rt_add_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_dst, d_src, n);
 }
 extern "C" void rt_launch_finalize(const float* d_accum, float inv_n, size_t image_floats, float* d_out, hipStream_t stream) {
     uint32_t blocks = (uint32_t)((image_floats + 255) / 256);

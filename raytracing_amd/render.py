@@ -204,8 +204,48 @@ class DeviceScene:
         return rad
 
 
+class DeviceGroup:
+    """The scene on several GPUs of one host process (rt_group_create): render() deals the pattern columns to them,
+    sums their accumulators on the first device (RCCL, or peer copies with RT_AMD_REDUCE=peer) and returns the image.
+    devices: a list of device numbers (a number may appear twice: several shards on one GPU), None = every visible GPU."""
+
+    def __init__(self, world, devices=None):
+        self.world = list(world)
+        bvh = build_bvh_scene(SceneManager(self.world))
+        desc, keep = flatten_scene(self.world, bvh)
+        self.handle = C.c_void_p()
+        dev = np.ascontiguousarray(devices if devices is not None else [], dtype=np.int32)
+        ffi.check(ffi.lib().rt_group_create(C.byref(desc), ffi.iptr(dev) if len(dev) else None, len(dev), C.byref(self.handle)))
+        del keep
+        n = C.c_int(0)
+        ffi.check(ffi.lib().rt_group_size(self.handle, C.byref(n)))
+        self.n_devices = n.value
+
+    def close(self):
+        if self.handle:
+            ffi.lib().rt_group_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, camera, pattern, background, width, height, max_depth=50, seed=DEFAULT_SEED, flags=0):
+        """Returns (img, stats) like DeviceScene.render."""
+        pat, n = _pattern(pattern)
+        bg = np.asarray(background, dtype=F)
+        out = np.zeros(3 * width * height, dtype=F)
+        st = ffi.rtStats()
+        cam = camera_record(camera)
+        ffi.check(ffi.lib().rt_group_render(self.handle, C.byref(cam), ffi.fptr(pat), n, ffi.fptr(bg), width, height,
+                                            max_depth, seed, flags, ffi.fptr(out), C.byref(st)))
+        return out.reshape(width, height, 3).transpose(1, 0, 2).copy(), st
+
+
 def render(world, material=None, *, width=None, height=None, camera=None, background=None, pattern=None,
-           gpu=False, spp=None, seed=DEFAULT_SEED, device=0, **kwargs):
+           gpu=False, spp=None, seed=DEFAULT_SEED, device=0, devices=None, **kwargs):
     """render(world::Vector{<:Hittable}; ...), render(filename, material; ...) and render(key::Symbol; ...)
     (main.jl:21-96).  Defaults as main.jl:22-27: 1280x720, Camera(), sky-blue background, MSAA_S16.
     Returns an (height, width, 3) float32 image, row 0 = top, sqrt-gamma, unclamped."""
@@ -229,7 +269,11 @@ def render(world, material=None, *, width=None, height=None, camera=None, backgr
     if not gpu:
         raise NotImplementedError("gpu=False is the reference's own Julia CPU path; this package only provides "
                                   "the MI355X path (gpu=True)")
-    scene = DeviceScene(world, device=device)
+    # devices: a list of GPUs to spread the samples over (rt_group_*), "all" = every visible GPU; default: the one `device`
+    if devices is not None:
+        scene = DeviceGroup(world, devices=None if isinstance(devices, str) and devices == "all" else devices)
+    else:
+        scene = DeviceScene(world, device=device)
     try:
         img, _ = scene.render(opts["camera"], opts["pattern"], opts["background"], opts["width"], opts["height"],
                               seed=seed)

@@ -231,6 +231,59 @@ def test_sample_sharding_sums_to_the_full_frame(scenes):
         np.testing.assert_allclose(img, full, rtol=2e-6, atol=1e-7)
 
 
+def test_group_of_devices_in_one_process(scenes, monkeypatch):
+    """rt_group_*: one host process, several members.  With one GPU to test on: a group of one device is rt_render bit for
+    bit; the same with the sum forced through RCCL (a communicator of one: librccl is loaded, initialised and called);
+    three members on the one GPU (three host threads, three shards, peer copies and adds in member order) give the sum of
+    the three shards in that order bit for bit, i.e. the full frame up to the order of the FP32 sums."""
+    import torch
+    world, kw, dev, ref = scenes("cu_cover2")
+    cam, bg = kw["camera"], kw["background"]
+    pat = rt.Halton_sequence32(12)
+    W, H = 64, 48
+    full, _ = dev.render(cam, pat, bg, W, H)
+    one = rt.DeviceGroup(world, devices=[0])
+    try:
+        assert one.n_devices == 1
+        img, st = one.render(cam, pat, bg, W, H)
+        np.testing.assert_array_equal(bits(img), bits(full))
+        assert st.paths == W * H * 12 and st.seconds > 0
+        monkeypatch.setenv("RT_AMD_FORCE_RCCL", "1")
+        img, _ = one.render(cam, pat, bg, W, H)
+        monkeypatch.delenv("RT_AMD_FORCE_RCCL")
+        np.testing.assert_array_equal(bits(img), bits(full))
+    finally:
+        one.close()
+    three = rt.DeviceGroup(world, devices=[0, 0, 0])
+    try:
+        assert three.n_devices == 3
+        img, _ = three.render(cam, pat, bg, W, H)
+        again, _ = three.render(cam, pat, bg, W, H)
+    finally:
+        three.close()
+    np.testing.assert_array_equal(bits(img), bits(again))
+    np.testing.assert_allclose(img, full, rtol=2e-6, atol=1e-7)
+    stream = torch.cuda.current_stream().cuda_stream
+    total = torch.zeros(3 * W * H, dtype=torch.float32, device="cuda")
+    for r in range(3):
+        acc = torch.zeros(3 * W * H, dtype=torch.float32, device="cuda")
+        dev.accumulate(cam, pat, bg, W, H, acc.data_ptr(), sample_first=r, sample_stride=3, stream=stream)
+        torch.cuda.synchronize()
+        total = acc if r == 0 else total + acc
+    out = torch.zeros_like(total)
+    dev.finalize(total.data_ptr(), 12, W, H, out.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(bits(img), bits(out.cpu().numpy().reshape(W, H, 3).transpose(1, 0, 2)))
+    # all visible devices: here one
+    every = rt.DeviceGroup(world)
+    try:
+        assert every.n_devices == torch.cuda.device_count()
+    finally:
+        every.close()
+    with pytest.raises(ffi.RtError):
+        rt.DeviceGroup(world, devices=[torch.cuda.device_count()])
+
+
 @pytest.mark.parametrize("name", ["cornell_smoke_box", "cu_cover2", "teapot"])
 def test_degenerate_rays_terminate_and_match(name, scenes):
     """zero, axis-parallel, huge, infinite and NaN ray components: the stackless walk must end (node indices only grow)

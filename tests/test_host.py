@@ -181,3 +181,23 @@ def test_flattened_description_and_validation():
     assert L.rt_bvh_build(0, None, None, None, None, None, None) == -1
     assert L.rt_render(None, None, None, 0, None, 0, 0, 0, 0, 0, None, None) == -1
     assert L.rt_trace_rays(None, None, 0, 0.0, 1.0, 0, None, None, None, None, None, None) == -1
+
+
+def test_group_entry_points_without_a_device():
+    """rt_group_*: argument checks, and without a GPU a clear RT_ENODEV instead of a crash"""
+    L = ffi.lib()
+    handle = C.c_void_p()
+    assert L.rt_group_create(None, None, 0, C.byref(handle)) == -1
+    n = C.c_int(0)
+    assert L.rt_group_size(None, C.byref(n)) == -1
+    assert L.rt_group_destroy(None) == 0
+    world, _ = rt.get_scene("cornell_box", spp=1)
+    desc, keep = flatten_scene(world, rt.build_bvh_scene(rt.SceneManager(world)))
+    count = C.c_int(0)
+    assert L.rt_device_count(C.byref(count)) == 0
+    bad = np.array([0, 1], np.int32)
+    assert L.rt_group_create(C.byref(desc), ffi.iptr(bad), -1, C.byref(handle)) == -1
+    if count.value == 0:
+        assert L.rt_group_create(C.byref(desc), None, 0, C.byref(handle)) == -2       # RT_ENODEV
+        assert b"no HIP device" in L.rt_last_error() and not handle
+    del keep
