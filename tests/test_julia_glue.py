@@ -1,0 +1,220 @@
+"""The Julia side of the boundary (julia/*.jl) cannot run in the build image (no julia), so it is held to the C ABI by
+text: the isbits structs of julia/librt_amd.jl against the C header (compiled here with gcc) and the ctypes mirror, field
+by field; every ccall against the declared entry points; block structure of the files; and the overlay script against a
+copy of the reference when the reference is at hand."""
+import ctypes as C
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+from raytracing_amd import _ffi as ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JULIA = os.path.join(ROOT, "julia")
+REFERENCE = "/root/reference"
+
+SCALARS = {"Int32": (4, 4), "UInt32": (4, 4), "Float32": (4, 4), "Float64": (8, 8), "UInt64": (8, 8), "Int64": (8, 8),
+           "UInt8": (1, 1), "Cint": (4, 4)}
+PAIRS = {"RtObject": "rtObject", "RtTransform": "rtTransform", "RtMaterial": "rtMaterial", "RtTexture": "rtTexture",
+         "RtImage": "rtImage", "RtPerlin": "rtPerlin", "RtMesh": "rtMesh", "RtBvh": "rtBvh", "RtSceneDesc": "rtSceneDesc",
+         "RtCamera": "rtCamera", "RtStats": "rtStats"}
+
+
+def julia_structs():
+    text = open(os.path.join(JULIA, "librt_amd.jl")).read()
+    out = {}
+    for m in re.finditer(r"^struct (\w+)\n(.*?)^end", text, flags=re.M | re.S):
+        fields = []
+        for line in m.group(2).splitlines():
+            line = line.split("#")[0].strip()
+            if line:
+                name, typ = line.split("::")
+                fields.append((name.strip(), typ.strip()))
+        out[m.group(1)] = fields
+    return out
+
+
+def size_align(typ):
+    if typ in SCALARS:
+        return SCALARS[typ]
+    if typ.startswith("Ptr{"):
+        return 8, 8
+    m = re.fullmatch(r"NTuple\{(\d+),\s*(\w+)\}", typ)
+    if m:
+        s, a = SCALARS[m.group(2)]
+        return int(m.group(1)) * s, a
+    raise AssertionError("unknown Julia field type " + typ)
+
+
+def layout(fields):
+    """offsets and total size of an isbits struct (C layout rules, which Julia follows for such structs)"""
+    off, worst, res = 0, 1, []
+    for name, typ in fields:
+        s, a = size_align(typ)
+        off = (off + a - 1) // a * a
+        res.append((name, off, s))
+        off += s
+        worst = max(worst, a)
+    return res, (off + worst - 1) // worst * worst
+
+
+def c_layouts(tmp_path):
+    """sizeof / offsetof of every struct of include/rt_amd.h, from gcc"""
+    fields = {c: [f for f, _ in getattr(ffi, c)._fields_] for c in PAIRS.values()}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "rt_amd.h"', 'int main(void) {']
+    for c, names in fields.items():
+        src.append('printf("%s %%zu\\n", sizeof(%s));' % (c, c))
+        for f in names:
+            src.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (c, f, c, f))
+    src.append("return 0; }")
+    cfile, exe = tmp_path / "layout.c", tmp_path / "layout"
+    cfile.write_text("\n".join(src))
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(cfile), "-o", str(exe)])
+    out = {}
+    for line in subprocess.check_output([str(exe)], text=True).splitlines():
+        k, v = line.split()
+        out[k] = int(v)
+    return out
+
+
+def test_julia_structs_match_the_header_and_ctypes(tmp_path):
+    structs = julia_structs()
+    in_c = c_layouts(tmp_path)
+    assert set(PAIRS) <= set(structs), set(PAIRS) - set(structs)
+    for jl, c in PAIRS.items():
+        ct = getattr(ffi, c)
+        offsets, size = layout(structs[jl])
+        assert [n for n, _, _ in offsets] == [n for n, _ in ct._fields_], (jl, "field names / order")
+        assert size == C.sizeof(ct) == in_c[c], (jl, size, C.sizeof(ct), in_c[c])
+        for name, off, fsize in offsets:
+            cf = getattr(ct, name)
+            assert off == cf.offset == in_c["%s.%s" % (c, name)], (jl, name, off, cf.offset)
+            assert fsize == cf.size, (jl, name, fsize, cf.size)
+    # Camera{Float32} (src/camera.jl:3-14: seven Vec3 and three scalars) is passed as it is where the library wants an rtCamera
+    assert C.sizeof(ffi.rtCamera) == 7 * 12 + 3 * 4
+
+
+def julia_sources():
+    return {n: open(os.path.join(JULIA, n)).read() for n in sorted(os.listdir(JULIA)) if n.endswith(".jl")}
+
+
+def test_status_codes_and_kinds_match_the_header():
+    header = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    text = julia_sources()["librt_amd.jl"]
+    status = re.search(r"typedef enum rtStatus \{(.*?)\}", header, flags=re.S).group(1)
+    codes = re.findall(r"(RT_\w+) = (-?\d+)", status)
+    assert len(codes) == 7
+    for name, value in codes:
+        m = re.search(r"const %s = Cint\((-?\d+)\)" % name, text)
+        assert m and int(m.group(1)) == int(value), name
+    kinds = dict(re.findall(r"(RT_[A-Z_]+) = (\d+)", header))
+    for names, values in re.findall(r"^const ((?:RT_\w+, )+RT_\w+) = (.+)$", text, flags=re.M):
+        for n, v in zip(names.split(", "), re.findall(r"Int32\((\d+)\)", values)):
+            assert kinds[n] == v, (n, kinds[n], v)
+
+
+def test_every_ccall_names_a_declared_entry_point_with_matching_arguments():
+    kind = {"Cint": C.c_int, "UInt64": C.c_uint64, "UInt32": C.c_uint32, "Cstring": C.c_char_p}
+    seen = set()
+    for name, text in julia_sources().items():
+        for m in re.finditer(r"ccall\(\(:(\w+), librt\), (\w+),\s*\(([^()]*)\)", text):
+            fn, ret, args = m.group(1), m.group(2), m.group(3)
+            assert fn in ffi.SYMBOLS, (name, fn)
+            seen.add(fn)
+            res, argtypes = ffi.SYMBOLS[fn]
+            assert (ret == "Cstring") == (res is C.c_char_p) and (ret == "Cint") == (res is C.c_int), (fn, ret)
+            # split the argument tuple at top-level commas
+            parts, depth, cur = [], 0, ""
+            for ch in args:
+                if ch == "," and depth == 0:
+                    parts.append(cur.strip()); cur = ""
+                else:
+                    depth += ch == "{"
+                    depth -= ch == "}"
+                    cur += ch
+            if cur.strip():
+                parts.append(cur.strip())
+            assert len(parts) == len(argtypes), (fn, parts, len(argtypes))
+            for p, a in zip(parts, argtypes):
+                if p.startswith(("Ptr{", "Ref{")):
+                    assert a is C.c_void_p or hasattr(a, "contents") or a is C.c_char_p, (fn, p, a)
+                else:
+                    assert kind[p] is a, (fn, p, a)
+    assert {"rt_scene_create", "rt_scene_destroy", "rt_render", "rt_group_create", "rt_group_render", "rt_group_destroy",
+            "rt_last_error", "rt_device_count"} <= seen
+
+
+def strip_code(text):
+    """Julia source without comments, strings and bracketed expressions (where `end` and `for` are not block words)"""
+    text = re.sub(r'"""(?:.|\n)*?"""', '""', text)
+    text = re.sub(r'"(?:\\.|[^"\\\n])*"', '""', text)
+    text = re.sub(r"#[^\n]*", "", text)
+    prev = None
+    while prev != text:
+        prev = text
+        text = re.sub(r"\[[^\[\]]*\]", "", text)
+    return text
+
+
+@pytest.mark.parametrize("name", sorted(n for n in os.listdir(JULIA) if n.endswith(".jl")))
+def test_blocks_are_closed(name):
+    code = strip_code(open(os.path.join(JULIA, name)).read())
+    opens = len(re.findall(r"(?<![\w.:])(?:function|struct|if|for|while|try|begin|do|let|module|quote|macro)(?![\w!])", code))
+    opens -= len(re.findall(r"(?<![\w.:])mutable\s+struct", code)) * 0      # (`mutable struct` opens one block: counted once)
+    closes = len(re.findall(r"(?<![\w.:])end(?![\w!])", code))
+    assert opens == closes, (name, opens, closes)
+    assert code.count("(") == code.count(")") and code.count("{") == code.count("}"), name
+
+
+def test_every_hittable_of_the_reference_has_an_add_method():
+    text = julia_sources()["cuscene_manager.jl"]
+    handled = set(re.findall(r"add_new!\(t::SceneTables, o::(\w+)\)", text))
+    assert handled == {"Sphere", "MovingSphere", "xy_rect", "xz_rect", "yz_rect", "Box", "Transform", "ConstantMedium", "BVHTree", "Mesh"}
+    textures = set(re.findall(r"add_texture!\(t::SceneTables, tex::(\w+)", text))
+    assert textures == {"SolidColor", "CheckerTexture", "ImageTexture", "NoiseTexture"}
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "src")), reason="the reference checkout is not on this machine")
+def test_overlay_applies_to_the_reference(tmp_path):
+    """julia/apply_overlay.py on a copy of the reference: every anchor is found, nothing of CUDA.jl / Adapt.jl is left in
+    code, the device file is included, and the field names the glue reads exist in the reference's structs."""
+    work = tmp_path / "ref"
+    shutil.copytree(REFERENCE, work)
+    for d, _, files in os.walk(work):
+        os.chmod(d, 0o755)
+        for f in files:
+            os.chmod(os.path.join(d, f), 0o644)
+    subprocess.check_call([sys.executable, os.path.join(JULIA, "apply_overlay.py"), str(work)])
+    with pytest.raises(subprocess.CalledProcessError):          # a second time the anchors are gone: it must say so, not mangle
+        subprocess.check_call([sys.executable, os.path.join(JULIA, "apply_overlay.py"), str(work)], stderr=subprocess.DEVNULL)
+    for d in (work / "src", work):
+        for f in sorted(os.listdir(d)):
+            if (not f.endswith(".jl") and f != "Project.toml") or f in ("librt_amd.jl", "cuBVH.jl", "cuscene_manager.jl", "Ray_Tracing_device.jl"):
+                continue            # (the four files of julia/ name what they replace in their comments)
+            code = re.sub(r"#[^\n]*", "", open(d / f).read())
+            code = re.sub(r'"""(?:.|\n)*?"""', "", code)
+            for word in ("CUDA", "Adapt", "CuArray", "CuDeviceArray", "CuBVHTree", "@cuda", "cu_trace", "draw_kernel"):
+                assert word not in code, (f, word)
+    rt = open(work / "src" / "Ray_Tracing.jl").read()
+    assert 'include("Ray_Tracing_device.jl")' in rt and "function trace(" in rt and "function draw!(img::Array{RGB{F},2}" in rt
+    assert 'include("hittable.jl")' in open(work / "src" / "BVH.jl").read()
+    assert "DeviceImage(F, height, width)" in open(work / "main.jl").read()
+    # the fields the glue reads, in the reference's own struct definitions
+    src = "".join(open(work / "src" / f).read() for f in os.listdir(work / "src") if f.endswith(".jl") and not f.startswith(("cu", "librt", "Ray_Tracing_device")))
+    want = {"Sphere": ["center", "radius", "material"], "MovingSphere": ["center0", "t0", "center1", "t1", "radius", "material"],
+            "xy_rect": ["x0", "x1", "y0", "y1", "k", "material"], "xz_rect": ["x0", "x1", "z0", "z1", "k", "material"],
+            "yz_rect": ["y0", "y1", "z0", "z1", "k", "material"], "Box": ["box_min", "box_max", "sides"],
+            "Transform": ["object", "xform", "inv_xform", "bbox"], "ConstantMedium": ["boundary", "phase_function", "neg_inv_density"],
+            "BVHTree": ["nodes", "objects"], "BVHNode": ["box", "left", "right", "is_leaf"], "Mesh": ["vertices", "materials", "indices"],
+            "Vertex": ["position", "normal", "u", "v"], "Material": ["type", "albedo", "fuzz", "eta"], "Perlin3": ["random", "perm_x", "perm_y", "perm_z"],
+            "NoiseTexture": ["noise", "scale"], "CheckerTexture": ["odd", "even"], "ImageTexture": ["image"], "SolidColor": ["color"],
+            "Camera": ["origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w", "lens_radius", "t0", "t1"]}
+    for struct, names in want.items():
+        m = re.search(r"struct %s(?:\{[^\n]*)?(?: <: [^\n]*)?\n(.*?)\nend" % struct, src, flags=re.S)
+        assert m, struct
+        have = re.findall(r"^\s+(\w+)::", m.group(1), flags=re.M)
+        assert have[:len(names)] == names, (struct, have)
