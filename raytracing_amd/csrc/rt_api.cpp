@@ -85,6 +85,7 @@ int upload_nodes(rtScene* s) {
     s->dev.n_nodes = H.nodes_per_layout;
     s->dev.far_set = H.n_sets == 2 ? 8u * H.nodes_per_layout : 0u;
     for (int i = 0; i < 3; ++i) s->dev.centre[i] = H.centre[i];
+    for (int i = 0; i < 3; ++i) s->dev.middle[i] = H.middle[i];
     s->dev.radius2 = H.radius * H.radius;
     return RT_OK;
 }
@@ -156,6 +157,7 @@ int fill_params(const float background[3], int width, int height, int max_depth,
     P->fetch_threshold = (uint32_t)env_int("RT_AMD_FETCH_THRESHOLD", 28);
     P->step_dropout = (uint32_t)env_int("RT_AMD_STEP_DROPOUT", 12);
     P->regroup = std::getenv("RT_AMD_NO_REGROUP") ? 0u : 1u;
+    if (!std::getenv("RT_AMD_NO_BIN")) P->regroup |= 2u;
     return RT_OK;
 }
 

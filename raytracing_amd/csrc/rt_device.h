@@ -80,6 +80,7 @@ struct DevScene {
     // far_set = 0: one set for every ray.
     uint32_t far_set;
     float centre[3], radius2;
+    float middle[3];             // a point with half of the scene's surface primitives on either side, axis by axis
     float node_scale, inv_node_scale; // power of two applied to the node boxes (and to the ray for the box test)
     uint32_t surface_root, surface_size; // root of the surface tree (layout-relative) and its node count (0: no surfaces)
     uint32_t nested;       // 1 if the scene holds nested trees (Transform{BVHTree})

@@ -695,6 +695,18 @@ void rt_build_nodes(HostScene* out, double reach) {
                 radius = std::min(radius, 387.0 * world_radius((H.items[k].leaf & RT_LEAF_PRIM_MASK) - 1u) - offset_from_centre(k));
         }
     }
+    for (int i = 0; i < 3; ++i) { // (used to sort rays by where they start: any point does, a central one sorts best)
+        std::vector<double> c;
+        for (size_t k = 0; k < n; ++k) {
+            const double m = 0.5 * ((double)loose[k].b[i] + (double)loose[k].b[3 + i]);
+            if (H.items[k].tree != 1u && std::isfinite(m)) c.push_back(m);
+        }
+        H.middle[i] = 0.0f;
+        if (!c.empty()) {
+            std::nth_element(c.begin(), c.begin() + c.size() / 2, c.end());
+            H.middle[i] = (float)c[c.size() / 2];
+        }
+    }
     const bool two_sets = radius > 0.0 && std::isfinite(radius);
     H.n_sets = two_sets ? 2u : 1u;
     H.radius = two_sets ? (float)(radius * 0.999) : INFINITY;

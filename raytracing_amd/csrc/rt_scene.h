@@ -27,6 +27,7 @@ struct HostScene {
     uint32_t nodes_per_layout = 0;
     uint32_t n_sets = 1;
     float centre[3] = {0.0f, 0.0f, 0.0f};
+    float middle[3] = {0.0f, 0.0f, 0.0f}; // median of the surface leaves' box centres, axis by axis
     float radius = __builtin_inff();
     double reach = 0.0;        // largest |coordinate| of a ray origin the node boxes were built for
     double scene_reach = 0.0;  // largest finite |coordinate| of the scene's own boxes
