@@ -39,6 +39,7 @@ if "extend" in pmc and "FETCH_SIZE" in pmc["extend"]:
     path = os.path.join(out, "hbm_traffic.json")
     cur = json.load(open(path)) if os.path.exists(path) else {}
     cur[scene] = per_launch
+    cur[scene + "_profile"] = tag
     cur[scene + "_note"] = "bytes per rt_extend_kernel launch: (2*FETCH_SIZE + WRITE_SIZE) KB over %d launches, %s" % (e["dispatches"], tag)
     # issue-side view of the same kernel: share of SIMD cycles with a VALU instruction in flight, and lanes active in it
     if all(k in e for k in ("SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE")):
