@@ -292,6 +292,18 @@ typedef struct rtLayout {
 } rtLayout;
 int rt_scene_layout(const rtSceneDesc* desc, rtLayout* info, uint32_t* nodes, size_t node_capacity,
                     int32_t* prim_top, size_t prim_capacity);
+/* The same of a scene that is on a device: the node sets as the kernels walk them, read back.  rt_scene_create builds the
+ * trees on the device itself (raytracing_amd/csrc/accel_device.hip: the surface-area heuristic top down, one
+ * workgroup per tree, then a layout kernel; RT_AMD_HOST_BUILD=1 in the environment: the host builder, as rt_scene_layout,
+ * which gives the same trees), where the
+ * reference builds its trees on the host (src/BVH.jl:65-96, src/mesh.jl:217-283).  `build`, if not NULL: the number of
+ * trees the device built (node sets x trees), their leaf depth and the time on the device (all 0 for a host build). */
+typedef struct rtBuildInfo {
+    uint32_t on_device, n_trees, max_depth;
+    float build_ms;
+} rtBuildInfo;
+int rt_scene_nodes(rtScene* scene, rtLayout* info, uint32_t* nodes, size_t node_capacity, int32_t* prim_top,
+                   size_t prim_capacity, rtBuildInfo* build);
 
 /* A scene description in one binary file.  The reference has no scene files -- its scenes are Julia functions
  * (the files of samples/, registered in scenes.jl:8-11) -- this is the data they hand to draw!: the tables and the trees of an

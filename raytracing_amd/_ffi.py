@@ -97,6 +97,10 @@ class rtLayout(C.Structure):
                 ("radius", C.c_float)]
 
 
+class rtBuildInfo(C.Structure):
+    _fields_ = [("on_device", C.c_uint32), ("n_trees", C.c_uint32), ("max_depth", C.c_uint32), ("build_ms", C.c_float)]
+
+
 class rtObjMesh(C.Structure):
     _fields_ = [("n_vertices", C.c_int32), ("n_triangles", C.c_int32), ("vertices", c_f32p), ("indices", c_i32p)]
 
@@ -134,6 +138,8 @@ SYMBOLS = {
     "rt_scene_desc_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(rtSceneDesc))]),
     "rt_scene_desc_free": (None, [C.POINTER(rtSceneDesc)]),
     "rt_perlin_generate": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint64), C.c_int32, C.POINTER(rtPerlin)]),
+    "rt_scene_nodes": (C.c_int, [C.c_void_p, C.POINTER(rtLayout), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_int32),
+                                 C.c_size_t, C.POINTER(rtBuildInfo)]),
     "rt_scene_layout": (C.c_int, [C.POINTER(rtSceneDesc), C.POINTER(rtLayout), C.POINTER(C.c_uint32), C.c_size_t,
                                   c_i32p, C.c_size_t]),
     "rt_bvh_build": (C.c_int, [C.c_int, c_f32p, c_i32p, c_f32p, c_i32p, c_i32p, c_u8p]),

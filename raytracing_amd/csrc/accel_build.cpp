@@ -4,6 +4,7 @@
 // boxes are walked does not change which primitive is the closest hit, so the device is free to walk a better tree:
 // one tree over all surfaces, split by the surface-area heuristic, children ordered front to back for the ray.
 #include "accel_build.h"
+#include "accel_half.h"
 
 #include <algorithm>
 #include <cmath>
@@ -199,47 +200,17 @@ void accel_build(std::vector<AccelItem>& items, AccelTree& tree) {
     }
 }
 
-// float -> IEEE half strictly below (up = false) or strictly above (up = true) x; +-infinity stay; NaN gives the
-// infinity of the rounding direction, so a box with a NaN bound stays unconstrained on that side.  Strictly: a ray that
-// runs inside a face of the reference's box (direction component 0, origin exactly on the plane: 0 * Inf = NaN in the
-// slab test, which the reference's comparisons then ignore) is strictly inside the stored box and never meets that NaN.
-uint16_t accel_half(float x, bool up) {
-    if (!(x == x)) return up ? 0x7C00u : 0xFC00u;
-    _Float16 hf = (_Float16)x; // round to nearest even
-    uint16_t h;
-    std::memcpy(&h, &hf, 2);
-    float back = (float)hf;
-    if (back == x && (h & 0x7FFFu) == 0x7C00u) return h; // infinite
-    if (up && back <= x) {        // one step toward +infinity
-        if (h == 0x8000u) h = 0x0001u;
-        else if (h & 0x8000u) h -= 1u;
-        else h += 1u;
-    } else if (!up && back >= x) { // one step toward -infinity
-        if (h == 0x0000u) h = 0x8001u;
-        else if (h & 0x8000u) h += 1u;
-        else h -= 1u;
-    }
-    return h;
-}
+uint16_t accel_half(float x, bool up) { return accel_half_bits(x, up); }
 
 void accel_emit(const AccelTree& tree, int octant, float scale, std::vector<uint4>& out) {
     if (tree.nodes.empty()) return;
-    // one word per axis: the plane a ray of this octant meets first in the low half, the other one in the high half
-    auto pack = [scale, octant](const float* b, uint32_t word) {
-        uint32_t w[3];
-        for (int a = 0; a < 3; ++a) {
-            uint32_t lo = accel_half(b[a] * scale, false), hi = accel_half(b[3 + a] * scale, true);
-            w[a] = ((octant >> a) & 1) ? (hi | (lo << 16)) : (lo | (hi << 16));
-        }
-        return make_uint4(w[0], w[1], w[2], word);
-    };
     std::vector<int32_t> stack;
     stack.push_back(0);
     while (!stack.empty()) {
         const AccelNode& nd = tree.nodes[(size_t)stack.back()];
         stack.pop_back();
         uint32_t idx = (uint32_t)out.size();
-        out.push_back(pack(nd.b, nd.leaf ? (RT_NODE_LEAF | nd.leaf) : idx + nd.size));
+        out.push_back(accel_pack_node(nd.b, octant, scale, nd.leaf ? (RT_NODE_LEAF | nd.leaf) : idx + nd.size));
         if (nd.leaf == 0) {
             int first = (octant >> nd.axis) & 1; // negative direction: the upper child is nearer
             stack.push_back(nd.child[1 - first]);

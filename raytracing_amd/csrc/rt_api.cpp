@@ -39,6 +39,8 @@ struct rtScene {
     DevScene dev{};
     HostScene host;              // the staged scene: its leaves and tables stay, for node sets built for a wider reach
     uint4* d_nodes = nullptr;    // room for two node sets
+    AccelDeviceStats build_stats{0u, 0u, 0.0f}; // of the last build of the trees on the device
+    AccelDeviceWorkspace* build_ws = nullptr;   // device memory of the tree builder, kept for rebuilds
     void* buffers[24] = {nullptr};
     int n_buffers = 0;
     // scratch owned by the handle, grown on demand
@@ -77,10 +79,19 @@ int env_int(const char* name, int fallback) {
 int upload_nodes(rtScene* s) {
     const HostScene& H = s->host;
     const size_t capacity = (size_t)16 * H.nodes_per_layout;
-    if (H.nodes.size() != (size_t)H.n_sets * 8u * H.nodes_per_layout || H.nodes.size() > capacity)
-        return rt_fail(RT_EINVAL, "internal: node sets of unexpected size");
     if (!s->d_nodes) HIP_TRY(hipMalloc((void**)&s->d_nodes, capacity ? capacity * sizeof(uint4) : 16));
-    if (!H.nodes.empty()) HIP_TRY(hipMemcpy(s->d_nodes, H.nodes.data(), H.nodes.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    if (!H.host_trees) {
+        // every node of every layout is written by the build: the trees of a layout fill it without gaps
+        int st = RT_OK;
+        if (!s->build_ws) st = accel_device_workspace_create(H.set_items[0].size(), H.device_trees.size(), &s->build_ws);
+        if (st == RT_OK)
+            st = accel_device_build(s->build_ws, H.set_items, H.n_sets, H.device_trees, H.nodes_per_layout, H.node_scale, s->d_nodes, &s->build_stats);
+        if (st != RT_OK) return st;
+    } else {
+        if (H.nodes.size() != (size_t)H.n_sets * 8u * H.nodes_per_layout || H.nodes.size() > capacity)
+            return rt_fail(RT_EINVAL, "internal: node sets of unexpected size");
+        if (!H.nodes.empty()) HIP_TRY(hipMemcpy(s->d_nodes, H.nodes.data(), H.nodes.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    }
     s->dev.nodes = s->d_nodes;
     s->dev.n_nodes = H.nodes_per_layout;
     s->dev.far_set = H.n_sets == 2 ? 8u * H.nodes_per_layout : 0u;
@@ -186,6 +197,7 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     rtScene* s = new (std::nothrow) rtScene();
     if (!s) return rt_fail(RT_ENOMEM, "out of host memory");
     HostScene& H = s->host;
+    H.host_trees = std::getenv("RT_AMD_HOST_BUILD") != nullptr; // default: the trees are built on the device
     int st = rt_flatten_scene(desc, &H);
     if (st != RT_OK) { delete s; return st; }
     int n = 0;
@@ -259,11 +271,41 @@ int rt_scene_layout(const rtSceneDesc* desc, rtLayout* info, uint32_t* nodes, si
     return RT_OK;
 }
 
+int rt_scene_nodes(rtScene* s, rtLayout* info, uint32_t* nodes, size_t node_capacity, int32_t* prim_top, size_t prim_capacity,
+                   rtBuildInfo* build) {
+    if (!s || !info) return rt_fail(RT_EINVAL, "rt_scene_nodes: null argument");
+    const HostScene& H = s->host;
+    info->nodes_per_layout = H.nodes_per_layout;
+    info->n_prims = (uint32_t)(H.prims.size() / 3);
+    info->surface_root = H.surface_root; info->surface_size = H.surface_size;
+    info->medium_root = H.medium_root; info->medium_size = H.medium_size;
+    info->nested = H.nested ? 1u : 0u;
+    info->node_scale = H.node_scale;
+    info->n_sets = H.n_sets;
+    for (int i = 0; i < 3; ++i) info->centre[i] = H.centre[i];
+    info->radius = H.radius;
+    const size_t n_nodes = (size_t)H.n_sets * 8u * H.nodes_per_layout;
+    if (nodes && node_capacity >= n_nodes && n_nodes) {
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(nodes, s->d_nodes, n_nodes * sizeof(uint4), hipMemcpyDeviceToHost));
+    }
+    if (prim_top && prim_capacity >= H.prim_top.size()) std::memcpy(prim_top, H.prim_top.data(), H.prim_top.size() * sizeof(int32_t));
+    if (build) {
+        build->on_device = H.host_trees ? 0u : 1u;
+        build->n_trees = s->build_stats.n_trees;
+        build->max_depth = s->build_stats.max_depth;
+        build->build_ms = s->build_stats.build_ms;
+    }
+    return RT_OK;
+}
+
 int rt_scene_destroy(rtScene* s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->device);
     for (int i = 0; i < s->n_buffers; ++i) (void)hipFree(s->buffers[i]);
     if (s->d_nodes) (void)hipFree(s->d_nodes);
+    accel_device_workspace_destroy(s->build_ws);
     if (s->d_pattern) (void)hipFree(s->d_pattern);
     if (s->d_radiance) (void)hipFree(s->d_radiance);
     if (s->d_pool) (void)hipFree(s->d_pool);

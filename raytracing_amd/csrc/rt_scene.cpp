@@ -752,6 +752,23 @@ void rt_build_nodes(HostScene* out, double reach) {
     const uint32_t n_trees = (uint32_t)H.tree_first.size();
     const uint32_t per_layout = H.nodes_per_layout;
     H.nodes.clear();
+    H.set_items[0].clear();
+    H.set_items[1].clear();
+    H.device_trees.clear();
+    if (!H.host_trees) {
+        for (uint32_t t = 0; t < n_trees; ++t) {
+            if (t == 1u) continue; // the constant media are a list, not a tree
+            AccelDeviceTree dt{(uint32_t)H.set_items[0].size(), 0u, H.tree_first[t]};
+            for (size_t k = 0; k < n; ++k)
+                if (H.items[k].tree == t) {
+                    H.set_items[0].push_back(tight[k]);
+                    if (two_sets) H.set_items[1].push_back(loose[k]);
+                    dt.n_items++;
+                }
+            if (dt.n_items) H.device_trees.push_back(dt);
+        }
+        return;
+    }
     H.nodes.reserve((size_t)H.n_sets * 8u * per_layout);
     for (uint32_t set = 0; set < H.n_sets; ++set) {
         const std::vector<AccelItem>& boxes = set == 0 ? tight : loose;

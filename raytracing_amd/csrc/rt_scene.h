@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/rt_amd.h"
+#include "accel_device.h"
 #include "rt_device.h"
 
 // One leaf of a device tree, as the scene description gives it: what rt_build_nodes turns into boxes.
@@ -24,6 +25,11 @@ struct HostScene {
     // valid for rays that start inside the ball (centre, radius); set 1 (present if n_sets == 2) the reference's own
     // boxes, valid for every ray that starts within `reach` of the origin.
     std::vector<uint4> nodes;
+    // host_trees == false: rt_build_nodes stops at the leaves' boxes (set_items, the items of a tree contiguous, trees
+    // as listed in device_trees) and leaves `nodes` empty: the trees are then built on the device (accel_device_build)
+    bool host_trees = true;
+    std::vector<AccelItem> set_items[2];
+    std::vector<AccelDeviceTree> device_trees;
     uint32_t nodes_per_layout = 0;
     uint32_t n_sets = 1;
     float centre[3] = {0.0f, 0.0f, 0.0f};

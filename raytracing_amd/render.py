@@ -74,6 +74,18 @@ class DeviceScene:
         self.handle = C.c_void_p()
         ffi.check(ffi.lib().rt_scene_create(C.byref(desc), int(device), C.byref(self.handle)))
 
+    def layout(self):
+        """The node sets as they are on the device (rt_scene_nodes): (info, nodes, prim_top, build) with info, nodes and
+        prim_top as scene_layout() returns them and build = rtBuildInfo (who built the trees, and how)."""
+        info, build = ffi.rtLayout(), ffi.rtBuildInfo()
+        L = ffi.lib()
+        ffi.check(L.rt_scene_nodes(self.handle, C.byref(info), None, 0, None, 0, None))
+        nodes = np.zeros((8 * info.n_sets, info.nodes_per_layout, 4), dtype=np.uint32)
+        prim_top = np.zeros(info.n_prims, dtype=np.int32)
+        ffi.check(L.rt_scene_nodes(self.handle, C.byref(info), nodes.ctypes.data_as(C.POINTER(C.c_uint32)), nodes.size // 4,
+                                   ffi.iptr(prim_top), prim_top.size, C.byref(build)))
+        return info, nodes, prim_top, build
+
     @classmethod
     def from_file(cls, path, device=0):
         """A scene written by save_scene (rt_scene_desc_load + rt_scene_create): no world list, no tree build."""

@@ -1,0 +1,110 @@
+"""The trees the library builds on the device (accel_device.hip: surface-area heuristic top down, one workgroup per tree,
+then a layout kernel), read back through rt_scene_nodes: they are the host builder's trees (rt_scene_layout) node for node,
+in every layout of every node set; they are held to the same invariants (tests/test_accel_layout.py: every primitive once
+per layout, links in range, pre-order consistency, enclosure, conservative culling); and the pictures do not depend on
+who built the trees."""
+import os
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  (first: its HIP runtime has to be the first in the process)
+
+import raytracing_amd as rt
+import test_accel_layout as TL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def device_layouts():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            world, kw = rt.get_scene(name, spp=1)
+            dev = rt.DeviceScene(world)
+            try:
+                info, nodes, prim_top, build = dev.layout()
+            finally:
+                dev.close()
+            assert build.on_device == 1 and build.n_trees >= 1 and build.max_depth >= 1, (build.on_device, build.n_trees)
+            print(name, "device build: trees", build.n_trees, "depth", build.max_depth, "ms", round(build.build_ms, 3))
+            cache[name] = (world, kw, info, nodes, prim_top)
+        return cache[name]
+    return get
+
+
+@pytest.mark.parametrize("name", TL.SCENES)
+def test_device_built_trees_structure_and_coverage(name, device_layouts):
+    TL.test_structure_and_coverage(name, device_layouts)
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke_box", "cu_cover2", "cover1"])
+def test_device_built_trees_never_cull_what_the_reference_visits(name, device_layouts):
+    TL.test_walk_never_culls_what_the_reference_visits(name, device_layouts)
+
+
+@pytest.mark.parametrize("name", TL.SCENES)
+def test_device_built_trees_are_the_host_builders(name, device_layouts):
+    world, kw, info, nodes, prim_top = device_layouts(name)
+    h_info, h_nodes, h_prim_top = TL.scene_layout(world)
+    assert (info.nodes_per_layout, info.n_sets, info.surface_root, info.surface_size) == \
+        (h_info.nodes_per_layout, h_info.n_sets, h_info.surface_root, h_info.surface_size)
+    assert np.array_equal(prim_top, h_prim_top)
+    assert np.array_equal(nodes, h_nodes), np.argwhere(nodes != h_nodes)[:8]
+
+
+def test_far_camera_rebuild_on_the_device():
+    """a camera far outside the scene makes the library rebuild the node sets for its distance (boxes of objects taken out
+    of nested trees are padded in proportion): with the device builder that is a kernel launch, and it gives what the
+    host builder gives for the same reach"""
+    world, kw = rt.get_scene("cover2", spp=1)
+    origin, target = np.array([30000.0, 20000.0, -40000.0]), np.array([278.0, 278.0, 0.0])
+    cam = rt.Camera(origin, origin - target, (0, 1, 0), 1.0, 1.0)
+    dev = rt.DeviceScene(world)
+    try:
+        before = dev.layout()[1]
+        img = dev.render(cam, kw["pattern"], kw["background"], 64, 64)[0]
+        after = dev.layout()[1]
+    finally:
+        dev.close()
+    assert not np.array_equal(before, after) and np.isfinite(img).all()
+    os.environ["RT_AMD_HOST_BUILD"] = "1"
+    try:
+        host = rt.DeviceScene(world)
+        try:
+            img_h = host.render(cam, kw["pattern"], kw["background"], 64, 64)[0]
+            after_h = host.layout()[1]
+        finally:
+            host.close()
+    finally:
+        del os.environ["RT_AMD_HOST_BUILD"]
+    assert np.array_equal(after, after_h) and np.array_equal(img.view(np.uint32), img_h.view(np.uint32))
+
+
+def test_device_build_is_deterministic():
+    world, kw = rt.get_scene("cu_cover2", spp=1)
+    a, b = rt.DeviceScene(world), rt.DeviceScene(world)
+    try:
+        na, nb = a.layout()[1], b.layout()[1]
+    finally:
+        a.close(); b.close()
+    assert np.array_equal(na, nb)
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "cu_cover2", "cover2", "teapot"])
+def test_pictures_do_not_depend_on_the_builder(name, monkeypatch):
+    world, kw = rt.get_scene(name, spp=4)
+    w, h = (kw["width"] // 4, kw["height"] // 4)
+
+    def picture():
+        dev = rt.DeviceScene(world)
+        try:
+            return dev.render(kw["camera"], kw["pattern"], kw["background"], w, h)[0], dev.layout()[3].on_device
+        finally:
+            dev.close()
+    img_dev, on_dev = picture()
+    monkeypatch.setenv("RT_AMD_HOST_BUILD", "1")
+    img_host, on_dev2 = picture()
+    assert on_dev == 1 and on_dev2 == 0
+    assert np.array_equal(img_dev.view(np.uint32), img_host.view(np.uint32))
