@@ -2,8 +2,8 @@
 //
 // The reference builds one median-split tree per object type on the host (src/BVH.jl:65-96; meshes
 // src/mesh.jl:217-283).  Which boxes a ray walks does not change which primitive is its closest hit, so the device
-// walks trees of its own, and here it also builds them, by the surface-area heuristic, top down, one workgroup per
-// tree (accel_sah_kernel):
+// walks trees of its own, and here it also builds them, by the surface-area heuristic, top down (accel_sah_kernel, one
+// workgroup per tree, down to ranges of 64 leaves; accel_sweep_kernel, a wave per such range):
 //   ranges of more than 64 leaves, level by level -- the largest with all threads on one range, the others a wave each:
 //     box and centroid bounds, 32 bins per axis (LDS atomics on order-preserving integer images of the floats), the
 //     cheapest of the 3 x 31 bin boundaries, a stable partition by prefix sums / ballots;
@@ -402,12 +402,12 @@ __device__ void split_by_wave(AccelItem* items, AccelItem* temp, WorkNode* nodes
 __global__ void __launch_bounds__(BUILD_THREADS) accel_sah_kernel(const AccelItem* __restrict__ items_in, const Job* __restrict__ jobs,
                                                                   WorkNode* __restrict__ work, AccelItem* __restrict__ items_all,
                                                                   AccelItem* __restrict__ temp_all, Range* __restrict__ queue_a,
-                                                                  Range* __restrict__ queue_b, Range* __restrict__ small_all) {
+                                                                  Range* __restrict__ queue_b, Range* __restrict__ small_all,
+                                                                  uint32_t* __restrict__ small_count) {
     __shared__ uint32_t box_image[6];
     __shared__ unsigned long long centroid_image[6];
     __shared__ uint32_t wave_bins[BUILD_THREADS / 64u][3][BINS][BIN_WORDS]; // the first wave's serve the whole workgroup too
     __shared__ uint32_t scan[BUILD_THREADS];
-    __shared__ uint32_t wave_stack[BUILD_THREADS / 64u][3u * SWEEP_LIMIT];
     __shared__ int split_axis, split_bin;
     __shared__ uint32_t n_next, n_small, n_alloc;
     const Job job = jobs[blockIdx.x];
@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(BUILD_THREADS) accel_sah_kernel(const AccelIte
     uint32_t (*bin_box)[BINS][BIN_WORDS] = wave_bins[0];
     const Counters counters{&n_alloc, &n_small, &n_next};
     if (n == 1u) {
-        if (tid == 0u) write_leaf(nodes, 0u, 0xFFFFFFFFu, items[0]);
+        if (tid == 0u) { write_leaf(nodes, 0u, 0xFFFFFFFFu, items[0]); small_count[blockIdx.x] = 0u; }
         return;
     }
     if (tid == 0u) {
@@ -588,9 +588,19 @@ __global__ void __launch_bounds__(BUILD_THREADS) accel_sah_kernel(const AccelIte
         Range* t = cur; cur = nxt; nxt = t;
         __syncthreads();
     }
-    // ---- ranges of up to SWEEP_LIMIT items: a wave each, down to the leaves
-    const uint32_t n_ranges = n_small;
-    for (uint32_t i = tid >> 6; i < n_ranges; i += BUILD_THREADS / 64u) build_small(items, nodes, small[i], wave_stack[tid >> 6]);
+    // ---- the ranges of up to SWEEP_LIMIT items are left to accel_sweep_kernel, which has the whole device for them
+    if (tid == 0u) small_count[blockIdx.x] = n_small;
+}
+
+// The ranges of up to SWEEP_LIMIT items that accel_sah_kernel listed for tree `j`: a wave each, down to the leaves.
+__global__ void __launch_bounds__(256) accel_sweep_kernel(const Job* __restrict__ jobs, uint32_t j, WorkNode* __restrict__ work,
+                                                          const AccelItem* __restrict__ items_all, const Range* __restrict__ small_all,
+                                                          const uint32_t* __restrict__ small_count) {
+    __shared__ uint32_t wave_stack[4][3u * SWEEP_LIMIT];
+    const Job job = jobs[j];
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wave >= small_count[j]) return;
+    build_small(items_all + job.item_first, work + job.node_first, small_all[job.item_first + wave], wave_stack[threadIdx.x >> 6]);
 }
 
 // A thread per (node, octant): the node's place in the octant's depth-first order, near child first, is the number of
@@ -637,7 +647,7 @@ struct AccelDeviceWorkspace {
     DevBuf<Job> jobs;
     DevBuf<WorkNode> work;
     DevBuf<Range> queue_a, queue_b, small;
-    DevBuf<uint32_t> depth;
+    DevBuf<uint32_t> depth, small_count;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ~AccelDeviceWorkspace() {
         if (e0) (void)hipEventDestroy(e0);
@@ -670,6 +680,7 @@ int accel_device_workspace_create(size_t n_items, size_t n_trees, AccelDeviceWor
     if (e == hipSuccess) e = ws->queue_b.alloc(n_all);
     if (e == hipSuccess) e = ws->small.alloc(n_all);
     if (e == hipSuccess) e = ws->depth.alloc(1);
+    if (e == hipSuccess) e = ws->small_count.alloc(2 * n_trees);
     if (e == hipSuccess) e = hipEventCreate(&ws->e0);
     if (e == hipSuccess) e = hipEventCreate(&ws->e1);
     if (e != hipSuccess) {
@@ -713,7 +724,12 @@ int accel_device_build(AccelDeviceWorkspace* ws, const std::vector<AccelItem>* i
     HIP_TRY(hipMemset(ws->depth.p, 0, sizeof(uint32_t)));
     HIP_TRY(hipEventRecord(ws->e0, nullptr));
     hipLaunchKernelGGL(accel_sah_kernel, dim3((uint32_t)jobs.size()), dim3(BUILD_THREADS), 0, nullptr, ws->items_in.p, ws->jobs.p, ws->work.p,
-                       ws->items.p, ws->temp.p, ws->queue_a.p, ws->queue_b.p, ws->small.p);
+                       ws->items.p, ws->temp.p, ws->queue_a.p, ws->queue_b.p, ws->small.p, ws->small_count.p);
+    for (uint32_t j = 0; j < (uint32_t)jobs.size(); ++j) { // (a listed range has at least two items)
+        const uint32_t waves = jobs[j].n_items / 2u;
+        if (waves) hipLaunchKernelGGL(accel_sweep_kernel, dim3((waves + 3u) / 4u), dim3(256), 0, nullptr, ws->jobs.p, j, ws->work.p, ws->items.p,
+                                      ws->small.p, ws->small_count.p);
+    }
     for (uint32_t j = 0; j < (uint32_t)jobs.size(); ++j) {
         const uint32_t threads = (2u * jobs[j].n_items - 1u) * 8u;
         hipLaunchKernelGGL(accel_layout_kernel, dim3((threads + 255u) / 256u), dim3(256), 0, nullptr, ws->work.p, ws->jobs.p, j, nodes_per_layout,
