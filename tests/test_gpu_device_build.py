@@ -82,6 +82,49 @@ def test_far_camera_rebuild_on_the_device():
     assert np.array_equal(after, after_h) and np.array_equal(img.view(np.uint32), img_h.view(np.uint32))
 
 
+def grid_mesh(n):
+    """a height field of 2 n^2 triangles"""
+    xs = np.linspace(-1, 1, n + 1, dtype=np.float32)
+    X, Z = np.meshgrid(xs, xs, indexing="ij")
+    V = np.zeros(((n + 1) ** 2, 8), np.float32)
+    V[:, 0], V[:, 1], V[:, 2] = X.ravel(), (0.1 * np.sin(5 * X) * np.cos(7 * Z)).ravel(), Z.ravel()
+    V[:, 4] = 1.0
+    V[:, 6:] = -1
+    idx = np.arange((n + 1) ** 2).reshape(n + 1, n + 1)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    z = np.zeros_like(a)
+    T = np.concatenate([np.stack([a, b, c, z], 1), np.stack([a, c, d, z], 1)]).astype(np.int32)
+    return rt.Mesh(V, [rt.Material(rt.Lambertian, rt.Vec3(0.7, 0.7, 0.7))], T)
+
+
+@pytest.mark.parametrize("n", [40, 181])
+def test_large_mesh_device_build_is_the_host_builders(n):
+    """3200 and 65 522 triangles: ranges that the whole workgroup splits over several levels, many centroids on common planes
+    (ties), and a picture through each tree"""
+    world = [grid_mesh(n)]
+    dev = rt.DeviceScene(world)
+    try:
+        info, nodes, prim_top, build = dev.layout()
+        cam = rt.Camera((0.0, 1.5, -3.0), (0.0, 1.5, -3.0), (0, 1, 0), 45.0, 1.0)
+        img = dev.render(cam, rt.Halton_sequence32(2), (0.7, 0.8, 1.0), 96, 96)[0]
+    finally:
+        dev.close()
+    assert build.on_device == 1 and info.nodes_per_layout == 4 * n * n - 1
+    print(2 * n * n, "triangles: device build", round(build.build_ms, 3), "ms, depth", build.max_depth)
+    h_info, h_nodes, _ = TL.scene_layout(world)
+    assert np.array_equal(nodes, h_nodes), np.argwhere(nodes != h_nodes)[:8]
+    os.environ["RT_AMD_HOST_BUILD"] = "1"
+    try:
+        host = rt.DeviceScene(world)
+        try:
+            img_h = host.render(cam, rt.Halton_sequence32(2), (0.7, 0.8, 1.0), 96, 96)[0]
+        finally:
+            host.close()
+    finally:
+        del os.environ["RT_AMD_HOST_BUILD"]
+    assert np.array_equal(img.view(np.uint32), img_h.view(np.uint32)) and img.std() > 0.01
+
+
 def test_device_build_is_deterministic():
     world, kw = rt.get_scene("cu_cover2", spp=1)
     a, b = rt.DeviceScene(world), rt.DeviceScene(world)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time of rt_scene_create (flattening on the host, upload, the device trees) with the trees built on the device and,
-RT_AMD_HOST_BUILD=1, by the host builder: python tools/build_time.py [scene ...]"""
+RT_AMD_HOST_BUILD=1, by the host builder: python tools/build_time.py [scene ...]; a scene "grid:N" is a height field of
+2 N^2 triangles."""
 import ctypes as C
 import os
 import sys
@@ -18,7 +19,12 @@ def main():
     names = sys.argv[1:] or ["cu_cover2", "cover1", "teapot"]
     L = ffi.lib()
     for name in names:
-        world = list(rt.get_scene(name, spp=1)[0])
+        if name.startswith("grid:"):
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+            from test_gpu_device_build import grid_mesh
+            world = [grid_mesh(int(name[5:]))]
+        else:
+            world = list(rt.get_scene(name, spp=1)[0])
         desc, keep = flatten_scene(world, build_bvh_scene(SceneManager(world)))
         for mode in ("device", "host", "device", "host"):
             if mode == "host":
