@@ -2,12 +2,15 @@
 //
 // The reference builds one median-split tree per object type on the host (src/BVH.jl:65-96; meshes
 // src/mesh.jl:217-283).  Which boxes a ray walks does not change which primitive is its closest hit, so the device
-// walks trees of its own, and here it also builds them, by the surface-area heuristic, top down (accel_sah_kernel, one
-// workgroup per tree, down to ranges of 64 leaves; accel_sweep_kernel, a wave per such range):
-//   ranges of more than 64 leaves, level by level -- the largest with all threads on one range, the others a wave each:
-//     box and centroid bounds, 32 bins per axis (LDS atomics on order-preserving integer images of the floats), the
-//     cheapest of the 3 x 31 bin boundaries, a stable partition by prefix sums / ballots;
-//   ranges of up to 64 leaves, a wave each with a leaf per lane, down to the leaves: sorted along every axis in turn
+// walks trees of its own, and here it also builds them, by the surface-area heuristic, top down, level by level (the
+// ranges of a level are independent: each gets a workgroup or a wave anywhere on the device; the host reads one count
+// per level):
+//   ranges of more than 64 leaves (accel_split_blocks_kernel: a workgroup per range of more than 2048,
+//     accel_split_waves_kernel: a wave per smaller one): box and centroid bounds, 32 bins per axis (LDS atomics on
+//     order-preserving integer images of the floats), the cheapest of the 3 x 31 bin boundaries, a stable partition by
+//     prefix sums / ballots;
+//   ranges of up to 64 leaves (accel_sweep_kernel), a wave each with a leaf per lane, down to the leaves: sorted along
+//     every axis in turn
 //     (ranks by comparison, ds_permute), every split position costed from prefix and suffix boxes (wave scans).
 // The arithmetic, the order of the candidates and the tie-breaks are those of the host builder (accel_build.cpp),
 // which stays for hosts without a GPU: both give the same tree, node for node (tests/test_gpu_device_build.py).
@@ -51,6 +54,7 @@ struct Range {
     uint32_t lo, hi;  // items [lo, hi) of the tree
     uint32_t node;    // the node that holds them
     uint32_t alloc;   // small ranges: first of the 2 (hi - lo) - 2 nodes reserved for the subtree
+    uint32_t job;     // the tree
 };
 
 constexpr int BINS = 32;
@@ -271,8 +275,8 @@ __device__ inline void hand_out_children(WorkNode* nodes, const AccelItem* items
         const uint32_t cm = ch[s] - cl[s];
         nodes[cn[s]].parent = (int32_t)r.node;
         if (cm == 1u) write_leaf(nodes, cn[s], r.node, items[cl[s]]);
-        else if (cm <= SWEEP_LIMIT) small[atomicAdd(C.n_small, 1u)] = Range{cl[s], ch[s], cn[s], atomicAdd(C.n_alloc, 2u * cm - 2u)};
-        else nxt[atomicAdd(C.n_next, 1u)] = Range{cl[s], ch[s], cn[s], 0u};
+        else if (cm <= SWEEP_LIMIT) small[atomicAdd(C.n_small, 1u)] = Range{cl[s], ch[s], cn[s], atomicAdd(C.n_alloc, 2u * cm - 2u), r.job};
+        else nxt[atomicAdd(C.n_next, 1u)] = Range{cl[s], ch[s], cn[s], 0u, r.job};
     }
 }
 
@@ -398,209 +402,201 @@ __device__ void split_by_wave(AccelItem* items, AccelItem* temp, WorkNode* nodes
     wave_sync_global();
 }
 
-// One workgroup per tree.  Node 0 is the root.
-__global__ void __launch_bounds__(BUILD_THREADS) accel_sah_kernel(const AccelItem* __restrict__ items_in, const Job* __restrict__ jobs,
-                                                                  WorkNode* __restrict__ work, AccelItem* __restrict__ items_all,
-                                                                  AccelItem* __restrict__ temp_all, Range* __restrict__ queue_a,
-                                                                  Range* __restrict__ queue_b, Range* __restrict__ small_all,
-                                                                  uint32_t* __restrict__ small_count) {
+// ctr[0] = ranges listed for the next level, ctr[1] = small ranges listed, ctr[2 + j] = nodes handed out in tree j
+__device__ inline Counters counters_of(uint32_t* ctr, uint32_t job) { return Counters{ctr + 2u + job, ctr + 1u, ctr}; }
+
+// The roots.  A workgroup per tree: the tree's items are copied (the build permutes them), node 0 is the root.
+__global__ void __launch_bounds__(256) accel_start_kernel(const AccelItem* __restrict__ items_in, const Job* __restrict__ jobs,
+                                                          WorkNode* __restrict__ work, AccelItem* __restrict__ items_all,
+                                                          Range* __restrict__ queue, Range* __restrict__ small, uint32_t* __restrict__ ctr) {
+    const Job job = jobs[blockIdx.x];
+    const uint32_t n = job.n_items;
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) items_all[job.item_first + i] = items_in[job.item_first + i];
+    if (threadIdx.x != 0u || n == 0u) return;
+    WorkNode* nodes = work + job.node_first;
+    nodes[0].parent = -1;
+    ctr[2u + blockIdx.x] = n <= SWEEP_LIMIT ? 2u * n - 1u : 1u;
+    if (n == 1u) write_leaf(nodes, 0u, 0xFFFFFFFFu, items_in[job.item_first]);
+    else if (n <= SWEEP_LIMIT) small[atomicAdd(ctr + 1u, 1u)] = Range{0u, n, 0u, 1u, blockIdx.x};
+    else queue[atomicAdd(ctr, 1u)] = Range{0u, n, 0u, 0u, blockIdx.x};
+}
+
+// One level of the ranges of more than WAVE_LIMIT items: a workgroup per listed range (binned split, accel_build.cpp
+// binned_split; the smaller ranges of the list are accel_split_waves_kernel's).
+__global__ void __launch_bounds__(BUILD_THREADS) accel_split_blocks_kernel(const Job* __restrict__ jobs, WorkNode* __restrict__ work,
+                                                                           AccelItem* __restrict__ items_all, AccelItem* __restrict__ temp_all,
+                                                                           const Range* __restrict__ cur, Range* __restrict__ nxt,
+                                                                           Range* __restrict__ small, uint32_t* __restrict__ ctr) {
     __shared__ uint32_t box_image[6];
     __shared__ unsigned long long centroid_image[6];
-    __shared__ uint32_t wave_bins[BUILD_THREADS / 64u][3][BINS][BIN_WORDS]; // the first wave's serve the whole workgroup too
+    __shared__ uint32_t bin_box[3][BINS][BIN_WORDS];
     __shared__ uint32_t scan[BUILD_THREADS];
     __shared__ int split_axis, split_bin;
-    __shared__ uint32_t n_next, n_small, n_alloc;
-    const Job job = jobs[blockIdx.x];
-    const uint32_t tid = threadIdx.x, n = job.n_items;
-    if (n == 0u) return;
+    const Range r = cur[blockIdx.x];
+    const uint32_t m = r.hi - r.lo, tid = threadIdx.x;
+    if (m <= WAVE_LIMIT) return;
+    const Job job = jobs[r.job];
     AccelItem* items = items_all + job.item_first;
     AccelItem* temp = temp_all + job.item_first;
     WorkNode* nodes = work + job.node_first;
-    Range* cur = queue_a + job.item_first;
-    Range* nxt = queue_b + job.item_first;
-    Range* small = small_all + job.item_first;
-    for (uint32_t i = tid; i < n; i += BUILD_THREADS) items[i] = items_in[job.item_first + i];
-    if (tid == 0u) {
-        n_next = 0u; n_small = 0u; n_alloc = 1u;
-        nodes[0].parent = -1;
+    if (tid < 6u) {
+        box_image[tid] = image32(tid < 3u ? INFINITY : -INFINITY);
+        centroid_image[tid] = image64(tid < 3u ? INFINITY : -INFINITY);
+    }
+    for (uint32_t i = tid; i < 3u * BINS; i += BUILD_THREADS) {
+        for (int a = 0; a < 6; ++a) bin_box[i / BINS][i % BINS][a] = image32(a < 3 ? INFINITY : -INFINITY);
+        bin_box[i / BINS][i % BINS][6] = 0u;
     }
     __syncthreads();
-    uint32_t n_cur = 0u;
-    uint32_t (*bin_box)[BINS][BIN_WORDS] = wave_bins[0];
-    const Counters counters{&n_alloc, &n_small, &n_next};
-    if (n == 1u) {
-        if (tid == 0u) { write_leaf(nodes, 0u, 0xFFFFFFFFu, items[0]); small_count[blockIdx.x] = 0u; }
-        return;
-    }
-    if (tid == 0u) {
-        const Range root{0u, n, 0u, 1u};
-        if (n <= SWEEP_LIMIT) { small[0] = root; n_small = 1u; n_alloc = 2u * n - 1u; }
-        else { cur[0] = root; }
-    }
-    n_cur = n > SWEEP_LIMIT ? 1u : 0u;
-    __syncthreads();
-    // ---- ranges of more than SWEEP_LIMIT items, level by level: binned splits.  The largest ones with all threads on
-    //      one range at a time, then the others a wave each.
-    while (n_cur) {
-        for (uint32_t q = 0; q < n_cur; ++q) {
-            const Range r = cur[q];
-            const uint32_t m = r.hi - r.lo;
-            if (m <= WAVE_LIMIT) continue;
-            if (tid < 6u) {
-                box_image[tid] = image32(tid < 3u ? INFINITY : -INFINITY);
-                centroid_image[tid] = image64(tid < 3u ? INFINITY : -INFINITY);
-            }
-            for (uint32_t i = tid; i < 3u * BINS; i += BUILD_THREADS) {
-                for (int a = 0; a < 6; ++a) bin_box[i / BINS][i % BINS][a] = image32(a < 3 ? INFINITY : -INFINITY);
-                bin_box[i / BINS][i % BINS][6] = 0u;
-            }
-            __syncthreads();
-            {   // bounds: per thread, per wave (shuffles), then one atomic per wave and bound
-                float tb[6];
-                double tl[3] = {INFINITY, INFINITY, INFINITY}, th[3] = {-INFINITY, -INFINITY, -INFINITY};
-                reset(tb);
-                for (uint32_t k = r.lo + tid; k < r.hi; k += BUILD_THREADS) {
-                    const AccelItem it = items[k];
-                    grow(tb, it.b);
-                    for (int a = 0; a < 3; ++a) {
-                        const double c = item_centroid(it, a);
-                        if (c < tl[a]) tl[a] = c;
-                        if (c > th[a]) th[a] = c;
-                    }
-                }
-                wave_box(tb);
-                wave_bounds(tl, th);
-                if ((tid & 63u) == 0u)
-                    for (int a = 0; a < 3; ++a) {
-                        atomicMin(&box_image[a], image32(tb[a]));
-                        atomicMax(&box_image[3 + a], image32(tb[3 + a]));
-                        atomicMin(&centroid_image[a], image64(tl[a]));
-                        atomicMax(&centroid_image[3 + a], image64(th[a]));
-                    }
-            }
-            __syncthreads();
-            double cmin[3], scale[3];
-            bool open[3];
+    {   // bounds: per thread, per wave (shuffles), then one atomic per wave and bound
+        float tb[6];
+        double tl[3] = {INFINITY, INFINITY, INFINITY}, th[3] = {-INFINITY, -INFINITY, -INFINITY};
+        reset(tb);
+        for (uint32_t k = r.lo + tid; k < r.hi; k += BUILD_THREADS) {
+            const AccelItem it = items[k];
+            grow(tb, it.b);
             for (int a = 0; a < 3; ++a) {
-                cmin[a] = number64(centroid_image[a]);
-                const double ext = number64(centroid_image[3 + a]) - cmin[a];
-                open[a] = ext > 0.0;
-                scale[a] = open[a] ? (double)BINS / ext : 0.0;
+                const double c = item_centroid(it, a);
+                if (c < tl[a]) tl[a] = c;
+                if (c > th[a]) th[a] = c;
             }
-            for (uint32_t k = r.lo + tid; k < r.hi; k += BUILD_THREADS) {
-                const AccelItem it = items[k];
-                for (int a = 0; a < 3; ++a) {
-                    if (!open[a]) continue;
-                    int b = (int)((item_centroid(it, a) - cmin[a]) * scale[a]);
-                    b = min(max(b, 0), BINS - 1);
-                    for (int c = 0; c < 3; ++c) {
-                        if (it.b[c] == it.b[c]) atomicMin(&bin_box[a][b][c], image32(it.b[c]));
-                        if (it.b[3 + c] == it.b[3 + c]) atomicMax(&bin_box[a][b][3 + c], image32(it.b[3 + c]));
-                    }
-                    atomicAdd(&bin_box[a][b][6], 1u);
-                }
+        }
+        wave_box(tb);
+        wave_bounds(tl, th);
+        if ((tid & 63u) == 0u)
+            for (int a = 0; a < 3; ++a) {
+                atomicMin(&box_image[a], image32(tb[a]));
+                atomicMax(&box_image[3 + a], image32(tb[3 + a]));
+                atomicMin(&centroid_image[a], image64(tl[a]));
+                atomicMax(&centroid_image[3 + a], image64(th[a]));
             }
+    }
+    __syncthreads();
+    double cmin[3], scale[3];
+    bool open[3];
+    for (int a = 0; a < 3; ++a) {
+        cmin[a] = number64(centroid_image[a]);
+        const double ext = number64(centroid_image[3 + a]) - cmin[a];
+        open[a] = ext > 0.0;
+        scale[a] = open[a] ? (double)BINS / ext : 0.0;
+    }
+    for (uint32_t k = r.lo + tid; k < r.hi; k += BUILD_THREADS) {
+        const AccelItem it = items[k];
+        for (int a = 0; a < 3; ++a) {
+            if (!open[a]) continue;
+            int b = (int)((item_centroid(it, a) - cmin[a]) * scale[a]);
+            b = min(max(b, 0), BINS - 1);
+            for (int c = 0; c < 3; ++c) {
+                if (it.b[c] == it.b[c]) atomicMin(&bin_box[a][b][c], image32(it.b[c]));
+                if (it.b[3 + c] == it.b[3 + c]) atomicMax(&bin_box[a][b][3 + c], image32(it.b[3 + c]));
+            }
+            atomicAdd(&bin_box[a][b][6], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0u) { // the cheapest bin boundary
+        double best = INFINITY;
+        int axis = -1, best_bin = 0;
+        for (int a = 0; a < 3; ++a) {
+            if (!open[a]) continue;
+            double ra[BINS];
+            uint32_t rc[BINS];
+            float rb[6];
+            reset(rb);
+            uint32_t c = 0u;
+            for (int b = BINS - 1; b >= 1; --b) {
+                float bb[6];
+                for (int k = 0; k < 6; ++k) bb[k] = number32(bin_box[a][b][k]);
+                grow(rb, bb);
+                c += bin_box[a][b][6];
+                ra[b] = half_area(rb);
+                rc[b] = c;
+            }
+            float lb[6];
+            reset(lb);
+            uint32_t lc = 0u;
+            for (int b = 1; b < BINS; ++b) {
+                float bb[6];
+                for (int k = 0; k < 6; ++k) bb[k] = number32(bin_box[a][b - 1][k]);
+                grow(lb, bb);
+                lc += bin_box[a][b - 1][6];
+                if (lc == 0u || rc[b] == 0u) continue;
+                const double cost = half_area(lb) * (double)lc + ra[b] * (double)rc[b];
+                if (cost < best) { best = cost; axis = a; best_bin = b; }
+            }
+        }
+        split_axis = axis;
+        split_bin = best_bin;
+    }
+    __syncthreads();
+    const int axis = split_axis;
+    uint32_t mid = r.lo + m / 2u; // every centroid coincides: halve the range
+    if (axis >= 0) {
+        // stable partition: items whose bin lies below the boundary first.  Each thread owns a run of places.
+        const int best_bin = split_bin;
+        const uint32_t run = (m + BUILD_THREADS - 1u) / BUILD_THREADS;
+        const uint32_t r0 = min(r.lo + tid * run, r.hi), r1 = min(r0 + run, r.hi);
+        uint32_t below = 0u;
+        for (uint32_t k = r0; k < r1; ++k) {
+            int b = (int)((item_centroid(items[k], axis) - cmin[axis]) * scale[axis]);
+            b = min(max(b, 0), BINS - 1);
+            below += b < best_bin ? 1u : 0u;
+        }
+        scan[tid] = below;
+        __syncthreads();
+        for (uint32_t off = 1; off < BUILD_THREADS; off <<= 1) {
+            const uint32_t v = tid >= off ? scan[tid - off] : 0u;
             __syncthreads();
-            if (tid == 0u) { // the cheapest bin boundary (accel_build.cpp, binned_split)
-                double best = INFINITY;
-                int axis = -1, best_bin = 0;
-                for (int a = 0; a < 3; ++a) {
-                    if (!open[a]) continue;
-                    double ra[BINS];
-                    uint32_t rc[BINS];
-                    float rb[6];
-                    reset(rb);
-                    uint32_t c = 0u;
-                    for (int b = BINS - 1; b >= 1; --b) {
-                        float bb[6];
-                        for (int k = 0; k < 6; ++k) bb[k] = number32(bin_box[a][b][k]);
-                        grow(rb, bb);
-                        c += bin_box[a][b][6];
-                        ra[b] = half_area(rb);
-                        rc[b] = c;
-                    }
-                    float lb[6];
-                    reset(lb);
-                    uint32_t lc = 0u;
-                    for (int b = 1; b < BINS; ++b) {
-                        float bb[6];
-                        for (int k = 0; k < 6; ++k) bb[k] = number32(bin_box[a][b - 1][k]);
-                        grow(lb, bb);
-                        lc += bin_box[a][b - 1][6];
-                        if (lc == 0u || rc[b] == 0u) continue;
-                        const double cost = half_area(lb) * (double)lc + ra[b] * (double)rc[b];
-                        if (cost < best) { best = cost; axis = a; best_bin = b; }
-                    }
-                }
-                split_axis = axis;
-                split_bin = best_bin;
-            }
-            __syncthreads();
-            const int axis = split_axis;
-            uint32_t mid = r.lo + m / 2u; // every centroid coincides: halve the range
-            if (axis >= 0) {
-                // stable partition: items whose bin lies below the boundary first.  Each thread owns a run of places.
-                const int best_bin = split_bin;
-                const uint32_t run = (m + BUILD_THREADS - 1u) / BUILD_THREADS;
-                const uint32_t r0 = min(r.lo + tid * run, r.hi), r1 = min(r0 + run, r.hi);
-                uint32_t below = 0u;
-                for (uint32_t k = r0; k < r1; ++k) {
-                    int b = (int)((item_centroid(items[k], axis) - cmin[axis]) * scale[axis]);
-                    b = min(max(b, 0), BINS - 1);
-                    below += b < best_bin ? 1u : 0u;
-                }
-                scan[tid] = below;
-                __syncthreads();
-                for (uint32_t off = 1; off < BUILD_THREADS; off <<= 1) {
-                    const uint32_t v = tid >= off ? scan[tid - off] : 0u;
-                    __syncthreads();
-                    scan[tid] += v;
-                    __syncthreads();
-                }
-                const uint32_t total = scan[BUILD_THREADS - 1u];
-                uint32_t at_low = r.lo + scan[tid] - below, at_high = r.lo + total + (r0 - r.lo) - (scan[tid] - below);
-                for (uint32_t k = r0; k < r1; ++k) {
-                    const AccelItem it = items[k];
-                    int b = (int)((item_centroid(it, axis) - cmin[axis]) * scale[axis]);
-                    b = min(max(b, 0), BINS - 1);
-                    if (b < best_bin) temp[at_low++] = it;
-                    else temp[at_high++] = it;
-                }
-                __syncthreads();
-                for (uint32_t k = r.lo + tid; k < r.hi; k += BUILD_THREADS) items[k] = temp[k];
-                mid = r.lo + total;
-                if (mid == r.lo || mid == r.hi) mid = r.lo + m / 2u;
-            }
-            __syncthreads();
-            if (tid == 0u) {
-                float box[6];
-                for (int a = 0; a < 6; ++a) box[a] = number32(box_image[a]);
-                hand_out_children(nodes, items, r, mid, axis, box, small, nxt, counters);
-            }
+            scan[tid] += v;
             __syncthreads();
         }
-        for (uint32_t q = tid >> 6; q < n_cur; q += BUILD_THREADS / 64u)
-            if (cur[q].hi - cur[q].lo <= WAVE_LIMIT) split_by_wave(items, temp, nodes, cur[q], wave_bins[tid >> 6], small, nxt, counters);
+        const uint32_t total = scan[BUILD_THREADS - 1u];
+        uint32_t at_low = r.lo + scan[tid] - below, at_high = r.lo + total + (r0 - r.lo) - (scan[tid] - below);
+        for (uint32_t k = r0; k < r1; ++k) {
+            const AccelItem it = items[k];
+            int b = (int)((item_centroid(it, axis) - cmin[axis]) * scale[axis]);
+            b = min(max(b, 0), BINS - 1);
+            if (b < best_bin) temp[at_low++] = it;
+            else temp[at_high++] = it;
+        }
         __syncthreads();
-        n_cur = n_next;
-        __syncthreads();
-        if (tid == 0u) n_next = 0u;
-        Range* t = cur; cur = nxt; nxt = t;
-        __syncthreads();
+        for (uint32_t k = r.lo + tid; k < r.hi; k += BUILD_THREADS) items[k] = temp[k];
+        mid = r.lo + total;
+        if (mid == r.lo || mid == r.hi) mid = r.lo + m / 2u;
     }
-    // ---- the ranges of up to SWEEP_LIMIT items are left to accel_sweep_kernel, which has the whole device for them
-    if (tid == 0u) small_count[blockIdx.x] = n_small;
+    __syncthreads();
+    if (tid == 0u) {
+        float box[6];
+        for (int a = 0; a < 6; ++a) box[a] = number32(box_image[a]);
+        hand_out_children(nodes, items, r, mid, axis, box, small, nxt, counters_of(ctr, r.job));
+    }
 }
 
-// The ranges of up to SWEEP_LIMIT items that accel_sah_kernel listed for tree `j`: a wave each, down to the leaves.
-__global__ void __launch_bounds__(256) accel_sweep_kernel(const Job* __restrict__ jobs, uint32_t j, WorkNode* __restrict__ work,
-                                                          const AccelItem* __restrict__ items_all, const Range* __restrict__ small_all,
-                                                          const uint32_t* __restrict__ small_count) {
-    __shared__ uint32_t wave_stack[4][3u * SWEEP_LIMIT];
-    const Job job = jobs[j];
+// The same level, the listed ranges of up to WAVE_LIMIT items: a wave each.
+__global__ void __launch_bounds__(256) accel_split_waves_kernel(const Job* __restrict__ jobs, WorkNode* __restrict__ work,
+                                                                AccelItem* __restrict__ items_all, AccelItem* __restrict__ temp_all,
+                                                                const Range* __restrict__ cur, uint32_t n_cur, Range* __restrict__ nxt,
+                                                                Range* __restrict__ small, uint32_t* __restrict__ ctr) {
+    __shared__ uint32_t wave_bins[4][3][BINS][BIN_WORDS];
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (wave >= small_count[j]) return;
-    build_small(items_all + job.item_first, work + job.node_first, small_all[job.item_first + wave], wave_stack[threadIdx.x >> 6]);
+    if (wave >= n_cur) return;
+    const Range r = cur[wave];
+    if (r.hi - r.lo > WAVE_LIMIT) return;
+    const Job job = jobs[r.job];
+    split_by_wave(items_all + job.item_first, temp_all + job.item_first, work + job.node_first, r, wave_bins[threadIdx.x >> 6], small, nxt,
+                  counters_of(ctr, r.job));
+}
+
+// The listed ranges of up to SWEEP_LIMIT items: a wave each, down to the leaves.
+__global__ void __launch_bounds__(256) accel_sweep_kernel(const Job* __restrict__ jobs, WorkNode* __restrict__ work,
+                                                          const AccelItem* __restrict__ items_all, const Range* __restrict__ small,
+                                                          uint32_t n_small) {
+    __shared__ uint32_t wave_stack[4][3u * SWEEP_LIMIT];
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wave >= n_small) return;
+    const Range r = small[wave];
+    const Job job = jobs[r.job];
+    build_small(items_all + job.item_first, work + job.node_first, r, wave_stack[threadIdx.x >> 6]);
 }
 
 // A thread per (node, octant): the node's place in the octant's depth-first order, near child first, is the number of
@@ -647,7 +643,7 @@ struct AccelDeviceWorkspace {
     DevBuf<Job> jobs;
     DevBuf<WorkNode> work;
     DevBuf<Range> queue_a, queue_b, small;
-    DevBuf<uint32_t> depth, small_count;
+    DevBuf<uint32_t> depth, counters; // counters: see counters_of()
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ~AccelDeviceWorkspace() {
         if (e0) (void)hipEventDestroy(e0);
@@ -680,7 +676,7 @@ int accel_device_workspace_create(size_t n_items, size_t n_trees, AccelDeviceWor
     if (e == hipSuccess) e = ws->queue_b.alloc(n_all);
     if (e == hipSuccess) e = ws->small.alloc(n_all);
     if (e == hipSuccess) e = ws->depth.alloc(1);
-    if (e == hipSuccess) e = ws->small_count.alloc(2 * n_trees);
+    if (e == hipSuccess) e = ws->counters.alloc(2 + 2 * n_trees);
     if (e == hipSuccess) e = hipEventCreate(&ws->e0);
     if (e == hipSuccess) e = hipEventCreate(&ws->e1);
     if (e != hipSuccess) {
@@ -722,14 +718,30 @@ int accel_device_build(AccelDeviceWorkspace* ws, const std::vector<AccelItem>* i
         HIP_TRY(hipMemcpy(ws->items_in.p + s * n_items, items[s].data(), n_items * sizeof(AccelItem), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ws->jobs.p, jobs.data(), jobs.size() * sizeof(Job), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(ws->depth.p, 0, sizeof(uint32_t)));
+    HIP_TRY(hipMemset(ws->counters.p, 0, (2 + jobs.size()) * sizeof(uint32_t)));
     HIP_TRY(hipEventRecord(ws->e0, nullptr));
-    hipLaunchKernelGGL(accel_sah_kernel, dim3((uint32_t)jobs.size()), dim3(BUILD_THREADS), 0, nullptr, ws->items_in.p, ws->jobs.p, ws->work.p,
-                       ws->items.p, ws->temp.p, ws->queue_a.p, ws->queue_b.p, ws->small.p, ws->small_count.p);
-    for (uint32_t j = 0; j < (uint32_t)jobs.size(); ++j) { // (a listed range has at least two items)
-        const uint32_t waves = jobs[j].n_items / 2u;
-        if (waves) hipLaunchKernelGGL(accel_sweep_kernel, dim3((waves + 3u) / 4u), dim3(256), 0, nullptr, ws->jobs.p, j, ws->work.p, ws->items.p,
-                                      ws->small.p, ws->small_count.p);
+    hipLaunchKernelGGL(accel_start_kernel, dim3((uint32_t)jobs.size()), dim3(256), 0, nullptr, ws->items_in.p, ws->jobs.p, ws->work.p, ws->items.p,
+                       ws->queue_a.p, ws->small.p, ws->counters.p);
+    // level by level: the ranges of a level are independent, so each gets a workgroup or a wave of its own anywhere on
+    // the device; the host reads how many the level listed for the next one
+    Range *cur = ws->queue_a.p, *nxt = ws->queue_b.p;
+    uint32_t counts[2] = {0u, 0u}; // {ranges of the next level, small ranges so far}
+    for (uint32_t level = 0;; ++level) {
+        HIP_TRY(hipMemcpy(counts, ws->counters.p, sizeof(counts), hipMemcpyDeviceToHost));
+        const uint32_t n_cur = counts[0];
+        if (n_cur == 0u) break;
+        if (n_cur > n_sets * n_items || level > 4096u) return rt_fail(RT_EHIP, "internal: the device tree builder lost count of its ranges");
+        HIP_TRY(hipMemset(ws->counters.p, 0, sizeof(uint32_t)));
+        hipLaunchKernelGGL(accel_split_blocks_kernel, dim3(n_cur), dim3(BUILD_THREADS), 0, nullptr, ws->jobs.p, ws->work.p, ws->items.p, ws->temp.p,
+                           cur, nxt, ws->small.p, ws->counters.p);
+        hipLaunchKernelGGL(accel_split_waves_kernel, dim3((n_cur + 3u) / 4u), dim3(256), 0, nullptr, ws->jobs.p, ws->work.p, ws->items.p, ws->temp.p,
+                           cur, n_cur, nxt, ws->small.p, ws->counters.p);
+        std::swap(cur, nxt);
     }
+    if (counts[1] > n_sets * n_items) return rt_fail(RT_EHIP, "internal: the device tree builder lost count of its ranges");
+    if (counts[1])
+        hipLaunchKernelGGL(accel_sweep_kernel, dim3((counts[1] + 3u) / 4u), dim3(256), 0, nullptr, ws->jobs.p, ws->work.p, ws->items.p, ws->small.p,
+                           counts[1]);
     for (uint32_t j = 0; j < (uint32_t)jobs.size(); ++j) {
         const uint32_t threads = (2u * jobs[j].n_items - 1u) * 8u;
         hipLaunchKernelGGL(accel_layout_kernel, dim3((threads + 255u) / 256u), dim3(256), 0, nullptr, ws->work.p, ws->jobs.p, j, nodes_per_layout,
