@@ -293,8 +293,8 @@ typedef struct rtLayout {
 int rt_scene_layout(const rtSceneDesc* desc, rtLayout* info, uint32_t* nodes, size_t node_capacity,
                     int32_t* prim_top, size_t prim_capacity);
 /* The same of a scene that is on a device: the node sets as the kernels walk them, read back.  rt_scene_create builds the
- * trees on the device itself (raytracing_amd/csrc/accel_device.hip: the surface-area heuristic top down, one
- * workgroup per tree, then a layout kernel; RT_AMD_HOST_BUILD=1 in the environment: the host builder, as rt_scene_layout,
+ * trees on the device itself (raytracing_amd/csrc/accel_device.hip: the surface-area heuristic top down, level by
+ * level, then a layout kernel; RT_AMD_HOST_BUILD=1 in the environment: the host builder, as rt_scene_layout,
  * which gives the same trees), where the
  * reference builds its trees on the host (src/BVH.jl:65-96, src/mesh.jl:217-283).  `build`, if not NULL: the number of
  * trees the device built (node sets x trees), their leaf depth and the time on the device (all 0 for a host build). */

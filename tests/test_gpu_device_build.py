@@ -1,5 +1,5 @@
-"""The trees the library builds on the device (accel_device.hip: surface-area heuristic top down, one workgroup per tree,
-then a layout kernel), read back through rt_scene_nodes: they are the host builder's trees (rt_scene_layout) node for node,
+"""The trees the library builds on the device (accel_device.hip: surface-area heuristic top down, level by level, then a
+layout kernel), read back through rt_scene_nodes: they are the host builder's trees (rt_scene_layout) node for node,
 in every layout of every node set; they are held to the same invariants (tests/test_accel_layout.py: every primitive once
 per layout, links in range, pre-order consistency, enclosure, conservative culling); and the pictures do not depend on
 who built the trees."""
