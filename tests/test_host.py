@@ -181,6 +181,9 @@ def test_flattened_description_and_validation():
     assert L.rt_bvh_build(0, None, None, None, None, None, None) == -1
     assert L.rt_render(None, None, None, 0, None, 0, 0, 0, 0, 0, None, None) == -1
     assert L.rt_trace_rays(None, None, 0, 0.0, 1.0, 0, None, None, None, None, None, None) == -1
+    info = ffi.rtLayout()
+    assert L.rt_scene_nodes(None, C.byref(info), None, 0, None, 0, None) == -1
+    assert b"rt_scene_nodes" in L.rt_last_error()
 
 
 def test_group_entry_points_without_a_device():
