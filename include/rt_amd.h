@@ -304,6 +304,13 @@ typedef struct rtBuildInfo {
 } rtBuildInfo;
 int rt_scene_nodes(rtScene* scene, rtLayout* info, uint32_t* nodes, size_t node_capacity, int32_t* prim_top,
                    size_t prim_capacity, rtBuildInfo* build);
+/* The tree of surfaces once more, as the pair nodes a walk with a stack reads (one record of eight words per interior
+ * node: {box of the near child, word}, {box of the far child, word}; n_sets * 8 layouts of *pairs_per_layout records;
+ * raytracing_amd/csrc/accel_build.h): as the host builder makes them / as they are on the device.  *depth: the deepest
+ * leaf; *in_use: 1 if rt_render walks them (no nested trees, tree no deeper than the stack).  `pairs` may be NULL; with
+ * too little capacity (in records) only the counts are filled. */
+int rt_scene_layout_pairs(const rtSceneDesc* desc, uint32_t* pairs_per_layout, uint32_t* depth, uint32_t* pairs, size_t capacity);
+int rt_scene_pairs(rtScene* scene, uint32_t* pairs_per_layout, uint32_t* in_use, uint32_t* pairs, size_t capacity);
 
 /* A scene description in one binary file.  The reference has no scene files -- its scenes are Julia functions
  * (the files of samples/, registered in scenes.jl:8-11) -- this is the data they hand to draw!: the tables and the trees of an

@@ -140,6 +140,9 @@ SYMBOLS = {
     "rt_perlin_generate": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint64), C.c_int32, C.POINTER(rtPerlin)]),
     "rt_scene_nodes": (C.c_int, [C.c_void_p, C.POINTER(rtLayout), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_int32),
                                  C.c_size_t, C.POINTER(rtBuildInfo)]),
+    "rt_scene_layout_pairs": (C.c_int, [C.POINTER(rtSceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                        C.c_size_t]),
+    "rt_scene_pairs": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t]),
     "rt_scene_layout": (C.c_int, [C.POINTER(rtSceneDesc), C.POINTER(rtLayout), C.POINTER(C.c_uint32), C.c_size_t,
                                   c_i32p, C.c_size_t]),
     "rt_bvh_build": (C.c_int, [C.c_int, c_f32p, c_i32p, c_f32p, c_i32p, c_i32p, c_u8p]),

@@ -202,6 +202,51 @@ void accel_build(std::vector<AccelItem>& items, AccelTree& tree) {
 
 uint16_t accel_half(float x, bool up) { return accel_half_bits(x, up); }
 
+uint32_t accel_emit_pairs(const AccelTree& tree, int octant, float scale, uint32_t base, std::vector<uint4>& out) {
+    if (tree.nodes.empty()) return 0;
+    auto word = [](const AccelNode& nd, uint32_t index) { return nd.leaf ? (RT_NODE_LEAF | nd.leaf) : index; };
+    if (tree.nodes[0].leaf) { // a single leaf: one record that holds it twice
+        const uint4 rec = accel_pack_node(tree.nodes[0].b, octant, scale, word(tree.nodes[0], 0));
+        out.push_back(rec);
+        out.push_back(rec);
+        return 1;
+    }
+    struct Visit { int32_t node; uint32_t index; };
+    std::vector<Visit> stack;
+    stack.push_back({0, base});
+    const size_t first = out.size();
+    const uint32_t n_records = (tree.nodes[0].size - 1u) / 2u;
+    out.resize(first + 2u * (size_t)n_records);
+    while (!stack.empty()) {
+        const Visit v = stack.back();
+        stack.pop_back();
+        const AccelNode& nd = tree.nodes[(size_t)v.node];
+        const int near_side = (octant >> nd.axis) & 1; // negative direction: the upper child is nearer
+        const AccelNode& near = tree.nodes[(size_t)nd.child[near_side]];
+        const AccelNode& far = tree.nodes[(size_t)nd.child[1 - near_side]];
+        // depth-first, near child first: the near child's record follows its parent's, the far child's comes after the
+        // near subtree's (size - 1) / 2 records
+        const uint32_t near_index = v.index + 1u, far_index = v.index + 1u + (near.size - 1u) / 2u;
+        out[first + 2u * (size_t)(v.index - base)] = accel_pack_node(near.b, octant, scale, word(near, near_index));
+        out[first + 2u * (size_t)(v.index - base) + 1u] = accel_pack_node(far.b, octant, scale, word(far, far_index));
+        if (!far.leaf) stack.push_back({nd.child[1 - near_side], far_index});
+        if (!near.leaf) stack.push_back({nd.child[near_side], near_index});
+    }
+    return n_records;
+}
+
+uint32_t accel_depth(const AccelTree& tree) {
+    if (tree.nodes.empty()) return 0;
+    std::vector<uint32_t> depth(tree.nodes.size(), 0u); // children have larger indices than their parent
+    uint32_t deepest = 0;
+    for (size_t k = 0; k < tree.nodes.size(); ++k) {
+        const AccelNode& nd = tree.nodes[k];
+        if (nd.leaf) { deepest = std::max(deepest, depth[k]); continue; }
+        depth[(size_t)nd.child[0]] = depth[(size_t)nd.child[1]] = depth[k] + 1u;
+    }
+    return deepest;
+}
+
 void accel_emit(const AccelTree& tree, int octant, float scale, std::vector<uint4>& out) {
     if (tree.nodes.empty()) return;
     std::vector<int32_t> stack;

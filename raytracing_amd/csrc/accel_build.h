@@ -38,6 +38,15 @@ void accel_build(std::vector<AccelItem>& items, AccelTree& tree);
 // direction component a is negative) comes first.
 void accel_emit(const AccelTree& tree, int octant, float scale, std::vector<uint4>& out);
 
+// The same tree as pair nodes, for a walk that keeps a stack: one record of two uint4 per interior node, {box of the
+// child on the near side for rays of `octant` (three words as above), word} and the same for the far child; a word is
+// RT_NODE_LEAF | leaf word for a leaf, else the index of the child's own record, counted from `base` on (records are
+// appended in depth-first order, near child first: the first one is the root's).  A tree of one leaf gives one record
+// that holds the leaf twice.  Returns the number of records appended.
+uint32_t accel_emit_pairs(const AccelTree& tree, int octant, float scale, uint32_t base, std::vector<uint4>& out);
+// deepest leaf of the tree (root = 0)
+uint32_t accel_depth(const AccelTree& tree);
+
 // float -> IEEE half bits strictly below (up = false) or strictly above (up = true) x (infinities stay)
 uint16_t accel_half(float x, bool up);
 

@@ -14,6 +14,7 @@
 // [layout_first, layout_first + 2 n - 1) of each of the set's eight layouts.
 struct AccelDeviceTree {
     uint32_t item_first, n_items, layout_first;
+    bool pairs; // also written as pair nodes (accel_emit_pairs), at the start of each pair layout
 };
 
 struct AccelDeviceStats {
@@ -30,9 +31,10 @@ void accel_device_workspace_destroy(AccelDeviceWorkspace* ws);
 
 // Builds every tree of `trees` for each of the `n_sets` node sets (items[s]: the leaves of set s, the trees' items
 // contiguous) and writes the n_sets * 8 layouts of `nodes_per_layout` nodes to d_nodes (device memory of the current
-// device), boxes multiplied by `scale`.  Blocks until the nodes are there.  Returns an rtStatus.
+// device), boxes multiplied by `scale`; a tree marked `pairs` also goes to d_pairs, n_sets * 8 layouts of
+// `pairs_per_layout` records.  Blocks until the nodes are there.  Returns an rtStatus.
 int accel_device_build(AccelDeviceWorkspace* ws, const std::vector<AccelItem>* items, uint32_t n_sets,
                        const std::vector<AccelDeviceTree>& trees, uint32_t nodes_per_layout, float scale, uint4* d_nodes,
-                       AccelDeviceStats* stats);
+                       uint32_t pairs_per_layout, uint4* d_pairs, AccelDeviceStats* stats);
 
 #endif

@@ -47,7 +47,8 @@ struct Job {
     uint32_t layout_first;        // first node of the tree inside a layout
     uint32_t node_first;          // first of the tree's 2 n - 1 work nodes
     uint32_t set;
-    uint32_t pad[3];
+    uint32_t pairs;               // also written as pair nodes
+    uint32_t pad[2];
 };
 
 struct Range {
@@ -626,6 +627,43 @@ __global__ void __launch_bounds__(256) accel_layout_kernel(const WorkNode* __res
     if (o == 0u && nd.leaf) atomicMax(max_depth, depth);
 }
 
+// The same walk up for the pair nodes (accel_emit_pairs): a thread per (interior node, octant); the record's place is
+// the number of interior nodes before it in depth-first order, near child first -- a subtree of `size` nodes holds
+// (size - 1) / 2 of them.
+__global__ void __launch_bounds__(256) accel_pairs_kernel(const WorkNode* __restrict__ work, const Job* __restrict__ jobs, uint32_t j,
+                                                          uint32_t pairs_per_layout, float scale, uint4* __restrict__ out_pairs) {
+    const Job job = jobs[j];
+    const WorkNode* nodes = work + job.node_first;
+    const uint32_t n_nodes = 2u * job.n_items - 1u;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t v = idx >> 3, o = idx & 7u;
+    if (v >= n_nodes) return;
+    const WorkNode nd = nodes[v];
+    const uint32_t base = (job.set * 8u + o) * pairs_per_layout;
+    if (n_nodes == 1u) { // a single leaf: one record that holds it twice
+        const uint4 rec = accel_pack_node(nd.b, (int)o, scale, RT_NODE_LEAF | nd.leaf);
+        out_pairs[2u * base] = rec;
+        out_pairs[2u * base + 1u] = rec;
+        return;
+    }
+    if (nd.leaf) return;
+    uint32_t pos = 0u, depth = 0u, c = v;
+    while (c != 0u && depth < n_nodes) {
+        const uint32_t p = (uint32_t)nodes[c].parent;
+        if (p >= n_nodes) return;
+        const uint32_t near = (uint32_t)nodes[p].child[(o >> nodes[p].axis) & 1u];
+        if (c != near) pos += (nodes[near].size - 1u) / 2u;
+        pos += 1u;
+        c = p;
+        depth++;
+    }
+    const uint32_t side = (o >> nd.axis) & 1u;
+    const WorkNode near = nodes[nd.child[side]], far = nodes[nd.child[1u - side]];
+    const uint32_t at = base + pos, near_at = at + 1u, far_at = at + 1u + (near.size - 1u) / 2u;
+    out_pairs[2u * at] = accel_pack_node(near.b, (int)o, scale, near.leaf ? (RT_NODE_LEAF | near.leaf) : near_at);
+    out_pairs[2u * at + 1u] = accel_pack_node(far.b, (int)o, scale, far.leaf ? (RT_NODE_LEAF | far.leaf) : far_at);
+}
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -691,7 +729,7 @@ void accel_device_workspace_destroy(AccelDeviceWorkspace* ws) { delete ws; }
 
 int accel_device_build(AccelDeviceWorkspace* ws, const std::vector<AccelItem>* items, uint32_t n_sets,
                        const std::vector<AccelDeviceTree>& trees, uint32_t nodes_per_layout, float scale, uint4* d_nodes,
-                       AccelDeviceStats* stats) {
+                       uint32_t pairs_per_layout, uint4* d_pairs, AccelDeviceStats* stats) {
     if (stats) *stats = AccelDeviceStats{0u, 0u, 0.0f};
     if (!ws || !items || n_sets < 1u || n_sets > 2u || !d_nodes) return rt_fail(RT_EINVAL, "accel_device_build: bad argument");
     const size_t n_items = items[0].size();
@@ -710,6 +748,7 @@ int accel_device_build(AccelDeviceWorkspace* ws, const std::vector<AccelItem>* i
             j.layout_first = t.layout_first;
             j.node_first = (uint32_t)n_work;
             j.set = s;
+            j.pairs = t.pairs && d_pairs && pairs_per_layout >= (t.n_items > 1u ? t.n_items - 1u : 1u) ? 1u : 0u;
             n_work += 2u * (size_t)t.n_items - 1u;
             jobs.push_back(j);
         }
@@ -746,6 +785,9 @@ int accel_device_build(AccelDeviceWorkspace* ws, const std::vector<AccelItem>* i
         const uint32_t threads = (2u * jobs[j].n_items - 1u) * 8u;
         hipLaunchKernelGGL(accel_layout_kernel, dim3((threads + 255u) / 256u), dim3(256), 0, nullptr, ws->work.p, ws->jobs.p, j, nodes_per_layout,
                            scale, d_nodes, ws->depth.p);
+        if (jobs[j].pairs)
+            hipLaunchKernelGGL(accel_pairs_kernel, dim3((threads + 255u) / 256u), dim3(256), 0, nullptr, ws->work.p, ws->jobs.p, j,
+                               pairs_per_layout, scale, d_pairs);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ws->e1, nullptr));

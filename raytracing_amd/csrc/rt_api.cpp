@@ -39,6 +39,7 @@ struct rtScene {
     DevScene dev{};
     HostScene host;              // the staged scene: its leaves and tables stay, for node sets built for a wider reach
     uint4* d_nodes = nullptr;    // room for two node sets
+    uint4* d_pairs = nullptr;    // the tree of surfaces as pair nodes, room for two sets (null: the scene has none)
     AccelDeviceStats build_stats{0u, 0u, 0.0f}; // of the last build of the trees on the device
     AccelDeviceWorkspace* build_ws = nullptr;   // device memory of the tree builder, kept for rebuilds
     void* buffers[24] = {nullptr};
@@ -80,18 +81,29 @@ int upload_nodes(rtScene* s) {
     const HostScene& H = s->host;
     const size_t capacity = (size_t)16 * H.nodes_per_layout;
     if (!s->d_nodes) HIP_TRY(hipMalloc((void**)&s->d_nodes, capacity ? capacity * sizeof(uint4) : 16));
+    if (!s->d_pairs && H.pairs_per_layout) HIP_TRY(hipMalloc((void**)&s->d_pairs, (size_t)32 * H.pairs_per_layout * sizeof(uint4)));
+    uint32_t depth = H.tree_depth;
     if (!H.host_trees) {
         // every node of every layout is written by the build: the trees of a layout fill it without gaps
         int st = RT_OK;
         if (!s->build_ws) st = accel_device_workspace_create(H.set_items[0].size(), H.device_trees.size(), &s->build_ws);
         if (st == RT_OK)
-            st = accel_device_build(s->build_ws, H.set_items, H.n_sets, H.device_trees, H.nodes_per_layout, H.node_scale, s->d_nodes, &s->build_stats);
+            st = accel_device_build(s->build_ws, H.set_items, H.n_sets, H.device_trees, H.nodes_per_layout, H.node_scale, s->d_nodes,
+                                    H.pairs_per_layout, s->d_pairs, &s->build_stats);
         if (st != RT_OK) return st;
+        depth = s->build_stats.max_depth;
     } else {
         if (H.nodes.size() != (size_t)H.n_sets * 8u * H.nodes_per_layout || H.nodes.size() > capacity)
             return rt_fail(RT_EINVAL, "internal: node sets of unexpected size");
         if (!H.nodes.empty()) HIP_TRY(hipMemcpy(s->d_nodes, H.nodes.data(), H.nodes.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        if (H.pairs.size() != (size_t)H.n_sets * 16u * H.pairs_per_layout) return rt_fail(RT_EINVAL, "internal: pair nodes of unexpected size");
+        if (!H.pairs.empty()) HIP_TRY(hipMemcpy(s->d_pairs, H.pairs.data(), H.pairs.size() * sizeof(uint4), hipMemcpyHostToDevice));
     }
+    // rt_extend_kernel walks the pair nodes with a stack in LDS when the scene has them and the tree is no deeper than
+    // the stack (a lane pushes at most one entry per level)
+    s->dev.pairs = s->d_pairs;
+    s->dev.n_pairs = H.pairs_per_layout;
+    s->dev.use_pairs = (H.pairs_per_layout && depth <= RT_PAIR_STACK && !std::getenv("RT_AMD_NO_PAIRS")) ? 1u : 0u;
     s->dev.nodes = s->d_nodes;
     s->dev.n_nodes = H.nodes_per_layout;
     s->dev.far_set = H.n_sets == 2 ? 8u * H.nodes_per_layout : 0u;
@@ -164,7 +176,7 @@ int fill_params(const float background[3], int width, int height, int max_depth,
     P->background[0] = background[0]; P->background[1] = background[1]; P->background[2] = background[2];
     P->image_floats = (size_t)3 * (size_t)width * (size_t)height;
     P->leaf_threshold = (uint32_t)env_int("RT_AMD_LEAF_THRESHOLD", 24);
-    P->blocked_threshold = (uint32_t)env_int("RT_AMD_BLOCKED_THRESHOLD", 12);
+    P->blocked_threshold = (uint32_t)env_int("RT_AMD_BLOCKED_THRESHOLD", 20);
     P->fetch_threshold = (uint32_t)env_int("RT_AMD_FETCH_THRESHOLD", 28);
     P->step_dropout = (uint32_t)env_int("RT_AMD_STEP_DROPOUT", 12);
     P->regroup = std::getenv("RT_AMD_NO_REGROUP") ? 0u : 1u;
@@ -271,6 +283,31 @@ int rt_scene_layout(const rtSceneDesc* desc, rtLayout* info, uint32_t* nodes, si
     return RT_OK;
 }
 
+int rt_scene_layout_pairs(const rtSceneDesc* desc, uint32_t* pairs_per_layout, uint32_t* depth, uint32_t* pairs, size_t capacity) {
+    if (!desc || !pairs_per_layout) return rt_fail(RT_EINVAL, "rt_scene_layout_pairs: null argument");
+    HostScene H;
+    int st = rt_flatten_scene(desc, &H);
+    if (st != RT_OK) return st;
+    *pairs_per_layout = H.pairs_per_layout;
+    if (depth) *depth = H.tree_depth;
+    if (pairs && capacity >= H.pairs.size() / 2u) std::memcpy(pairs, H.pairs.data(), H.pairs.size() * sizeof(uint4));
+    return RT_OK;
+}
+
+int rt_scene_pairs(rtScene* s, uint32_t* pairs_per_layout, uint32_t* in_use, uint32_t* pairs, size_t capacity) {
+    if (!s || !pairs_per_layout) return rt_fail(RT_EINVAL, "rt_scene_pairs: null argument");
+    const HostScene& H = s->host;
+    *pairs_per_layout = H.pairs_per_layout;
+    if (in_use) *in_use = s->dev.use_pairs;
+    const size_t n_records = (size_t)H.n_sets * 8u * H.pairs_per_layout;
+    if (pairs && capacity >= n_records && n_records) {
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(pairs, s->d_pairs, n_records * 2u * sizeof(uint4), hipMemcpyDeviceToHost));
+    }
+    return RT_OK;
+}
+
 int rt_scene_nodes(rtScene* s, rtLayout* info, uint32_t* nodes, size_t node_capacity, int32_t* prim_top, size_t prim_capacity,
                    rtBuildInfo* build) {
     if (!s || !info) return rt_fail(RT_EINVAL, "rt_scene_nodes: null argument");
@@ -305,6 +342,7 @@ int rt_scene_destroy(rtScene* s) {
     (void)hipSetDevice(s->device);
     for (int i = 0; i < s->n_buffers; ++i) (void)hipFree(s->buffers[i]);
     if (s->d_nodes) (void)hipFree(s->d_nodes);
+    if (s->d_pairs) (void)hipFree(s->d_pairs);
     accel_device_workspace_destroy(s->build_ws);
     if (s->d_pattern) (void)hipFree(s->d_pattern);
     if (s->d_radiance) (void)hipFree(s->d_radiance);

@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #define RT_NODE_NONE 0xFFFFFFFFu    // "no node" (e.g. no outer tree to return to)
+#define RT_PAIR_STACK 20u          // entries of the LDS stack of a lane that walks the pair nodes: deepest tree walked that way
 #define RT_NODE_LEAF 0x80000000u    // node link word: the node is a leaf
 #define RT_LEAF_INSTANCE 0x40000000u // leaf word flag: the primitive is a nested tree (Transform{BVHTree})
 #define RT_LEAF_XFORM 0x20000000u    // leaf word flag: the primitive sits in a Transform (prim_inv holds its inverse matrix)
@@ -58,6 +59,8 @@ struct DevImage {
 
 struct DevScene {
     const uint4* nodes;
+    const uint4* pairs;          // the tree of surfaces as pair nodes: two uint4 per record, {near child's box, word}, {far child's box, word}
+    uint32_t n_pairs, use_pairs; // records per octant layout (second set: 8 * n_pairs further on); 1: rt_extend_kernel walks them
     const uint4* prims;
     const float4* prim_box;      // 4 per primitive: the boxes the reference walks for it (RT_BOX_* below)
     const float4* prim_inv;      // 3 per primitive: inverse 3x4 matrix (column-major) of its Transform, zeros without one

@@ -1565,7 +1565,8 @@ __global__ void __launch_bounds__(256) rt_init_kernel(RtCameraDev cam, const flo
 // Which block runs is a wave-wide vote.  Constant media are left to rt_shade_kernel.  NESTED: the scene holds nested
 // trees (Transform{BVHTree}); without them the state for the outer ray is not carried.
 #define LEAF_QUEUE 3u
-template <bool COUNT, bool NESTED>
+#define PAIR_LEAVES 3u // leaves a lane can have waiting in the walk over pair nodes (a step adds up to two)
+template <bool COUNT, bool NESTED, bool PAIRS>
 __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevScene S, RtRenderParams P, PathPool pool, uint32_t* __restrict__ head,
                                                         unsigned long long* __restrict__ counters) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -1587,6 +1588,15 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
     uint32_t node = 0, end = 0; // next node; the walk of the current tree is over at node == end
     uint32_t set = 0;           // node_set() of the ray (only kept where nested trees are entered)
     uint32_t q0 = 0, q1 = 0, q2 = 0, nq = 0; // leaf queue: q0 newest; entry nq - 1 is the oldest
+    // PAIRS (scenes without nested trees whose tree is no deeper than RT_PAIR_STACK): the walk reads pair nodes -- the
+    // boxes of both children of an interior node in one record -- and keeps the far child on a stack in LDS while it is in
+    // the near one's subtree: a third of the dependent fetches of the stackless walk (no fetch for a leaf, none for a
+    // box that is missed).  `node` is the record to read next, 0xFFFFFFFF (= `end`) when the walk is over.  The leaves
+    // found wait on a second small stack in LDS (a step can find two): in which order a lane's leaves are tested does
+    // not change its closest hit.  Both stacks take their stores unconditionally at the top; only the counts say what stays.
+    __shared__ uint32_t pair_stack[PAIRS ? RT_PAIR_STACK : 1u][256];
+    __shared__ uint32_t leaf_stack[PAIRS ? PAIR_LEAVES : 1u][256];
+    uint32_t sp = 0;
     Closest best = {INF, 0xFFFFFFFFu, 0u, 0u};
     for (;;) {
         // ---- end of a nested tree with nothing pending: back to the outer ray (cheap, no vote needed)
@@ -1599,7 +1609,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
         }
         const bool fin = busy && nq == 0u && node == end;
         const bool wl = busy && nq != 0u;
-        const bool ws = busy && node != end && nq < LEAF_QUEUE && !(NESTED && nq != 0u && (q0 & RT_LEAF_INSTANCE));
+        const bool ws = busy && node != end && (PAIRS ? nq + 2u <= PAIR_LEAVES : nq < LEAF_QUEUE) && !(NESTED && nq != 0u && (q0 & RT_LEAF_INSTANCE));
         const uint32_t n_need = (uint32_t)__popcll(__ballot(!busy || fin));
         const uint32_t nl = (uint32_t)__popcll(__ballot(wl));
         const uint32_t ns = (uint32_t)__popcll(__ballot(ws));
@@ -1655,8 +1665,15 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                                 time = p0.w;
                                 t_max = INF;
                                 set = node_set(S, o);
-                                node = S.surface_root + layout_base(S, d) + set;
-                                end = node + S.surface_size;
+                                if (PAIRS) {
+                                    const uint32_t octant = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
+                                    node = ((set ? 8u : 0u) + octant) * S.n_pairs;
+                                    end = 0xFFFFFFFFu;
+                                    sp = 0u;
+                                } else {
+                                    node = S.surface_root + layout_base(S, d) + set;
+                                    end = node + S.surface_size;
+                                }
                                 nq = 0u;
                                 ret = RT_NODE_NONE;
                                 inst_rank = 0; inst_xf = 0;
@@ -1676,7 +1693,9 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
         if (nl >= P.leaf_threshold || n_blocked >= P.blocked_threshold || ns == 0u) {
             if (wl) {
                 if (COUNT) { cnt.prims++; cnt.prim_waves += first_active_lane(); }
-                uint32_t e = nq == 3u ? q2 : (nq == 2u ? q1 : q0);
+                uint32_t e;
+                if (PAIRS) e = leaf_stack[nq - 1u][threadIdx.x];
+                else e = nq == 3u ? q2 : (nq == 2u ? q1 : q0);
                 nq -= 1u;
                 uint32_t prim = (e & RT_LEAF_PRIM_MASK) - 1u;
                 uint4 hd;
@@ -1722,7 +1741,34 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
             uint32_t n_step;
             bool stepping = ws;
             do {
-                if (stepping) {
+                if (PAIRS && stepping) {
+                    if (COUNT) { cnt.nodes += 2; cnt.node_waves += first_active_lane(); }
+                    const uint4* rec = S.pairs + ((size_t)node << 1);
+                    const uint4 qa = rec[0], qb = rec[1];
+                    const uint32_t top = pair_stack[sp ? sp - 1u : 0u][threadIdx.x]; // (wanted only if this step ends a subtree)
+                    bool hit2[2];
+                    for (int c = 0; c < 2; ++c) { // node_test() with t_max taken out of the min, for either child
+                        const uint4 q = c ? qb : qa;
+                        const v2h hx = __builtin_bit_cast(v2h, q.x), hy = __builtin_bit_cast(v2h, q.y), hz = __builtin_bit_cast(v2h, q.z);
+                        const float ax = __builtin_fmaf((float)hx.x, R.i.x, R.cn.x), fx = __builtin_fmaf((float)hx.y, R.i.x, R.cf.x);
+                        const float ay = __builtin_fmaf((float)hy.x, R.i.y, R.cn.y), fy = __builtin_fmaf((float)hy.y, R.i.y, R.cf.y);
+                        const float az = __builtin_fmaf((float)hz.x, R.i.z, R.cn.z), fz = __builtin_fmaf((float)hz.y, R.i.z, R.cf.z);
+                        const float tnear = fmaxf(fmaxf(ax, ay), fmaxf(az, t_min));
+                        float tfar = fminf(fminf(fx, fy), fz);
+                        tfar = __builtin_fmaf(fabsf(tfar), 4.8e-7f, tfar);
+                        hit2[c] = tnear <= tfar && tnear <= t_far;
+                    }
+                    const bool leaf_a = (int32_t)qa.w < 0, leaf_b = (int32_t)qb.w < 0;
+                    leaf_stack[nq][threadIdx.x] = qb.w; // the far leaf below the near one: the near one is tested first
+                    nq += (hit2[1] && leaf_b) ? 1u : 0u;
+                    leaf_stack[nq][threadIdx.x] = qa.w;
+                    nq += (hit2[0] && leaf_a) ? 1u : 0u;
+                    const bool go_a = hit2[0] && !leaf_a, go_b = hit2[1] && !leaf_b;
+                    pair_stack[sp][threadIdx.x] = qb.w; // (sp <= depth of the record read < RT_PAIR_STACK)
+                    node = go_a ? qa.w : (go_b ? qb.w : (sp ? top : 0xFFFFFFFFu));
+                    sp = sp + ((go_a && go_b) ? 1u : 0u) - ((!go_a && !go_b && sp != 0u) ? 1u : 0u);
+                }
+                if (!PAIRS && stepping) {
                     if (COUNT) { cnt.nodes++; cnt.node_waves += first_active_lane(); }
                     // node_test() with t_max taken out of the min
                     const uint4 q = S.nodes[node];
@@ -1746,7 +1792,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                 }
                 // from the lane's state (the same test as `ws` above), each comparison voted on its own: the votes are
                 // then the comparisons' lane masks themselves, combined by scalar instructions
-                const bool more = node != end, room = nq < LEAF_QUEUE;
+                const bool more = node != end, room = PAIRS ? nq + 2u <= PAIR_LEAVES : nq < LEAF_QUEUE;
                 const bool enter = NESTED && nq != 0u && (q0 & RT_LEAF_INSTANCE);
                 stepping = busy && more && room && !enter;
                 n_step = (uint32_t)__popcll(m_busy & __builtin_amdgcn_ballot_w64(more) & __builtin_amdgcn_ballot_w64(room) &
@@ -2232,11 +2278,13 @@ extern "C" void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, cons
     // timing (optional): three events, before extend / between / after shade
     uint32_t shade_blocks = (pool->n_slots + SHADE_BLOCK - 1u) / SHADE_BLOCK;
     if (timing) (void)hipEventRecord(timing[0], stream);
-    const bool nested = S->nested != 0u;
-    if (count && nested) hipLaunchKernelGGL((rt_extend_kernel<true, true>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
-    else if (count) hipLaunchKernelGGL((rt_extend_kernel<true, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
-    else if (nested) hipLaunchKernelGGL((rt_extend_kernel<false, true>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
-    else hipLaunchKernelGGL((rt_extend_kernel<false, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    const bool nested = S->nested != 0u, pairs = !nested && S->use_pairs != 0u;
+    if (count && nested) hipLaunchKernelGGL((rt_extend_kernel<true, true, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    else if (count && pairs) hipLaunchKernelGGL((rt_extend_kernel<true, false, true>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    else if (count) hipLaunchKernelGGL((rt_extend_kernel<true, false, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    else if (nested) hipLaunchKernelGGL((rt_extend_kernel<false, true, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    else if (pairs) hipLaunchKernelGGL((rt_extend_kernel<false, false, true>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    else hipLaunchKernelGGL((rt_extend_kernel<false, false, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
     if (before_shade) (void)hipStreamWaitEvent(stream, before_shade, 0);
     if (timing) (void)hipEventRecord(timing[1], stream);
     if (S->textured) hipLaunchKernelGGL(rt_shade_kernel<true>, dim3(shade_blocks), dim3(SHADE_BLOCK), 0, stream, *S, *cam, d_pattern, *P, *pool,

@@ -752,13 +752,20 @@ void rt_build_nodes(HostScene* out, double reach) {
     const uint32_t n_trees = (uint32_t)H.tree_first.size();
     const uint32_t per_layout = H.nodes_per_layout;
     H.nodes.clear();
+    H.pairs.clear();
+    H.tree_depth = 0;
+    {   // the tree of surfaces is also kept as pair nodes unless nested trees are walked (those enter and leave trees mid-walk)
+        size_t n_surfaces = 0;
+        for (size_t k = 0; k < n; ++k) n_surfaces += H.items[k].tree == 0u ? 1u : 0u;
+        H.pairs_per_layout = (H.nested || n_surfaces == 0) ? 0u : (uint32_t)std::max<size_t>(n_surfaces - 1u, 1u);
+    }
     H.set_items[0].clear();
     H.set_items[1].clear();
     H.device_trees.clear();
     if (!H.host_trees) {
         for (uint32_t t = 0; t < n_trees; ++t) {
             if (t == 1u) continue; // the constant media are a list, not a tree
-            AccelDeviceTree dt{(uint32_t)H.set_items[0].size(), 0u, H.tree_first[t]};
+            AccelDeviceTree dt{(uint32_t)H.set_items[0].size(), 0u, H.tree_first[t], t == 0u && H.pairs_per_layout != 0u};
             for (size_t k = 0; k < n; ++k)
                 if (H.items[k].tree == t) {
                     H.set_items[0].push_back(tight[k]);
@@ -770,6 +777,7 @@ void rt_build_nodes(HostScene* out, double reach) {
         return;
     }
     H.nodes.reserve((size_t)H.n_sets * 8u * per_layout);
+    H.pairs.reserve((size_t)H.n_sets * 16u * H.pairs_per_layout);
     for (uint32_t set = 0; set < H.n_sets; ++set) {
         const std::vector<AccelItem>& boxes = set == 0 ? tight : loose;
         std::vector<uint4> layout[8];
@@ -781,6 +789,10 @@ void rt_build_nodes(HostScene* out, double reach) {
             AccelTree tree;
             accel_build(items, tree);
             for (int o = 0; o < 8; ++o) accel_emit(tree, o, H.node_scale, layout[o]);
+            if (t == 0u && H.pairs_per_layout != 0u) {
+                for (int o = 0; o < 8; ++o) accel_emit_pairs(tree, o, H.node_scale, (set * 8u + (uint32_t)o) * H.pairs_per_layout, H.pairs);
+                H.tree_depth = std::max(H.tree_depth, accel_depth(tree));
+            }
         }
         for (uint32_t o = 0; o < 8; ++o) {
             // skip links (interior nodes) become absolute; leaf words stay

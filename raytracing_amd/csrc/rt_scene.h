@@ -25,6 +25,12 @@ struct HostScene {
     // valid for rays that start inside the ball (centre, radius); set 1 (present if n_sets == 2) the reference's own
     // boxes, valid for every ray that starts within `reach` of the origin.
     std::vector<uint4> nodes;
+    // The tree of surfaces once more as pair nodes (accel_emit_pairs), n_sets * 8 layouts of pairs_per_layout records of
+    // two uint4 (0: no surfaces, or nested trees present: those scenes are walked through `nodes` only); tree_depth: its
+    // deepest leaf (host_trees only; the device build reports its own).
+    std::vector<uint4> pairs;
+    uint32_t pairs_per_layout = 0;
+    uint32_t tree_depth = 0;
     // host_trees == false: rt_build_nodes stops at the leaves' boxes (set_items, the items of a tree contiguous, trees
     // as listed in device_trees) and leaves `nodes` empty: the trees are then built on the device (accel_device_build)
     bool host_trees = true;

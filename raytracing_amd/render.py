@@ -61,6 +61,23 @@ def scene_layout(world):
     return info, nodes, prim_top
 
 
+def scene_layout_pairs(world, n_sets):
+    """The tree of surfaces as pair nodes, as the host builder makes them (rt_scene_layout_pairs): (pairs, depth) with
+    pairs a (8 * n_sets, pairs_per_layout, 8) uint32 array -- words 0-2 the near child's box, 3 its word, 4-6 the far
+    child's box, 7 its word -- or an empty array if the scene has none (no surfaces, or nested trees)."""
+    world = list(world)
+    desc, keep = flatten_scene(world, build_bvh_scene(SceneManager(world)))
+    L = ffi.lib()
+    n, depth = C.c_uint32(0), C.c_uint32(0)
+    ffi.check(L.rt_scene_layout_pairs(C.byref(desc), C.byref(n), C.byref(depth), None, 0))
+    pairs = np.zeros((8 * n_sets, n.value, 8), dtype=np.uint32)
+    if pairs.size:
+        ffi.check(L.rt_scene_layout_pairs(C.byref(desc), C.byref(n), C.byref(depth), pairs.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                          pairs.size // 8))
+    del keep
+    return pairs, depth.value
+
+
 class DeviceScene:
     """What draw!(::CuArray, ...) builds before its kernel launch (src/Ray_Tracing.jl:144-145):
     bvh = build_bvh(world); cu_bvh = CuSceneManager(bvh) -- here a scene resident in one GPU's HBM."""
@@ -85,6 +102,17 @@ class DeviceScene:
         ffi.check(L.rt_scene_nodes(self.handle, C.byref(info), nodes.ctypes.data_as(C.POINTER(C.c_uint32)), nodes.size // 4,
                                    ffi.iptr(prim_top), prim_top.size, C.byref(build)))
         return info, nodes, prim_top, build
+
+    def pairs(self):
+        """The pair nodes as they are on the device (rt_scene_pairs): (pairs, in_use), pairs as scene_layout_pairs()"""
+        info = self.layout()[0]
+        L = ffi.lib()
+        n, used = C.c_uint32(0), C.c_uint32(0)
+        ffi.check(L.rt_scene_pairs(self.handle, C.byref(n), C.byref(used), None, 0))
+        pairs = np.zeros((8 * info.n_sets, n.value, 8), dtype=np.uint32)
+        if pairs.size:
+            ffi.check(L.rt_scene_pairs(self.handle, C.byref(n), C.byref(used), pairs.ctypes.data_as(C.POINTER(C.c_uint32)), pairs.size // 8))
+        return pairs, bool(used.value)
 
     @classmethod
     def from_file(cls, path, device=0):

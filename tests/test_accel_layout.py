@@ -8,7 +8,7 @@ import pytest
 
 import raytracing_amd as rt
 from raytracing_amd import hittables as H
-from raytracing_amd.render import scene_layout
+from raytracing_amd.render import scene_layout, scene_layout_pairs
 
 LEAF = 0x80000000
 PRIM_MASK = 0x1FFFFFFF
@@ -157,6 +157,86 @@ def walk(nodes, info, octant, root, size, o, d, t_min=0.001):
     return out
 
 
+def walk_pairs(pairs, info, octant, o, d, t_min=0.001, stack_limit=20):
+    """the walk of rt_extend_kernel over the pair nodes, with its stack: the same box test as walk(), on the two child boxes
+    of a record; a hit leaf is reported, a hit interior child is entered (the near one first, the far one waits on the
+    stack).  Returns (leaf words visited, deepest stack)."""
+    F = np.float32
+    scale = F(info.node_scale)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        inv = (F(1) / d).astype(F) * (F(1) / scale)
+        oi = ((o * scale).astype(F) * inv).astype(F)
+        slack = (np.abs(oi) * F(2.0 ** -22)).astype(F)
+        cn, cf = (-oi - slack).astype(F), (-oi + slack).astype(F)
+        rel = (o - np.asarray(info.centre, F)).astype(F)
+        inside = F(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]) < F(info.radius) * F(info.radius)
+    layout = (0 if inside else info.n_sets - 1) * 8 + octant
+    P = pairs.shape[1]
+    rec = pairs[layout]
+
+    def hit(words):
+        planes = words.copy().view(np.float16).astype(np.float64)
+        with np.errstate(invalid="ignore", over="ignore"):
+            t0 = (planes[0::2] * inv.astype(np.float64) + cn.astype(np.float64)).astype(F)
+            t1 = (planes[1::2] * inv.astype(np.float64) + cf.astype(np.float64)).astype(F)
+            tnear = max(np.fmax.reduce(t0), F(t_min))
+            tfar = np.fmin.reduce(t1)
+            tfar = tfar + abs(tfar) * F(4.8e-7)
+        return tnear <= tfar
+    out, stack, deepest = [], [], 0
+    cur = layout * P
+    while cur is not None:
+        r = rec[cur - layout * P]
+        go = []
+        for words, w in ((r[0:3], int(r[3])), (r[4:7], int(r[7]))):
+            if hit(words):
+                if w & LEAF:
+                    out.append(w & ~LEAF)
+                else:
+                    assert layout * P <= w < (layout + 1) * P
+                    go.append(w)
+        if len(go) == 2:
+            stack.append(go[1])
+            deepest = max(deepest, len(stack))
+        cur = go[0] if go else (stack.pop() if stack else None)
+    assert deepest <= stack_limit
+    return out, deepest
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke_box", "cu_cover2", "cover1", "teapot", "cover2"])
+def test_pair_nodes_structure(name, layouts):
+    """every record is reached exactly once from the first, every surface primitive is the leaf of exactly one child, and
+    the boxes are those of the 16-byte nodes (the same trees written down twice)"""
+    world, kw, info, nodes, prim_top = layouts(name)
+    pairs, depth = scene_layout_pairs(world, info.n_sets)
+    if info.nested:
+        assert pairs.size == 0
+        return
+    n_surfaces = sum(not isinstance(world[prim_top[k]], H.ConstantMedium) for k in range(info.n_prims))
+    P = max(n_surfaces - 1, 1)
+    assert pairs.shape == (8 * info.n_sets, P, 8) and 1 <= depth <= 40
+    for layout in range(8 * info.n_sets):
+        rec = pairs[layout]
+        seen = np.zeros(P, bool)
+        leaves = []
+        stack = [layout * P]
+        while stack:
+            i = stack.pop() - layout * P
+            assert 0 <= i < P and not seen[i]
+            seen[i] = True
+            for w in (int(rec[i, 3]), int(rec[i, 7])):
+                if w & LEAF:
+                    leaves.append((w & PRIM_MASK) - 1)
+                else:
+                    stack.append(w)
+        assert seen.all()
+        if n_surfaces > 1:
+            assert sorted(leaves) == sorted(k for k in range(info.n_prims) if not isinstance(world[prim_top[k]], H.ConstantMedium))
+        # the child boxes are node boxes of the same layout
+        node_boxes = {tuple(b) for b in nodes[layout, :, :3].tolist()}
+        assert all(tuple(b) in node_boxes for b in rec[:, 0:3].tolist()) and all(tuple(b) in node_boxes for b in rec[:, 4:7].tolist())
+
+
 def slab_exact(bmin, bmax, o, d, t_min=0.001):
     """src/bounding_box.jl:20-67 in float64"""
     tmin, tmax = float(t_min), np.inf
@@ -203,6 +283,7 @@ def must_visit(obj, o, d, tight, t_min=0.001):
 @pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke_box", "cu_cover2", "cover1"])
 def test_walk_never_culls_what_the_reference_visits(name, layouts):
     world, kw, info, nodes, prim_top = layouts(name)
+    pairs = layouts.pairs(name) if hasattr(layouts, "pairs") else scene_layout_pairs(world, info.n_sets)[0]
     rng = np.random.default_rng(7)
     cam = kw["camera"]
     boxes = [H.bounding_box(obj) for obj in world]
@@ -250,6 +331,9 @@ def test_walk_never_culls_what_the_reference_visits(name, layouts):
         for root, size in ((info.surface_root, info.surface_size), (info.medium_root, info.medium_size)):
             if size:
                 visited |= {prim_top[(w & PRIM_MASK) - 1] for w in walk(nodes, info, octant, root, size, o, d)}
+        if pairs is not None and pairs.size:
+            by_pairs = {prim_top[(w & PRIM_MASK) - 1] for w in walk_pairs(pairs, info, octant, o, d)[0]}
+            assert by_pairs == visited, (name, k)     # the same boxes, tested at the parent instead of at the node
         rel = o.astype(np.float64) - np.asarray(info.centre, np.float64)
         tight = info.n_sets == 2 and rel @ rel < 0.99 * float(info.radius) ** 2
         if info.n_sets == 2 and not tight and rel @ rel < 1.01 * float(info.radius) ** 2:

@@ -54,6 +54,41 @@ def test_device_built_trees_are_the_host_builders(name, device_layouts):
     assert np.array_equal(nodes, h_nodes), np.argwhere(nodes != h_nodes)[:8]
 
 
+@pytest.mark.parametrize("name", TL.SCENES)
+def test_device_built_pair_nodes_are_the_host_builders(name):
+    """the second form of the tree of surfaces (pair nodes, walked with a stack) as the device writes it and as the host
+    builder does"""
+    world, kw = rt.get_scene(name, spp=1)
+    dev = rt.DeviceScene(world)
+    try:
+        info = dev.layout()[0]
+        pairs, used = dev.pairs()
+    finally:
+        dev.close()
+    h_pairs, depth = TL.scene_layout_pairs(world, info.n_sets)
+    assert pairs.shape == h_pairs.shape and np.array_equal(pairs, h_pairs)
+    assert used == (pairs.size > 0 and depth <= 20)
+
+
+@pytest.mark.parametrize("name", ["cu_cover2", "cover1", "teapot"])
+def test_pictures_do_not_depend_on_the_walk(name, monkeypatch):
+    """the walk over pair nodes with a stack and the stackless walk over single nodes find the same closest hits"""
+    world, kw = rt.get_scene(name, spp=4)
+    w, h = (kw["width"] // 4, kw["height"] // 4)
+
+    def picture():
+        dev = rt.DeviceScene(world)
+        try:
+            return dev.render(kw["camera"], kw["pattern"], kw["background"], w, h)[0], dev.pairs()[1]
+        finally:
+            dev.close()
+    a, used_a = picture()
+    monkeypatch.setenv("RT_AMD_NO_PAIRS", "1")
+    b, used_b = picture()
+    assert used_a and not used_b
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_far_camera_rebuild_on_the_device():
     """a camera far outside the scene makes the library rebuild the node sets for its distance (boxes of objects taken out
     of nested trees are padded in proportion): with the device builder that is a kernel launch, and it gives what the
