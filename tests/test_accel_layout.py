@@ -2,7 +2,8 @@
 nodes; one set of tight boxes for rays that start inside the scene's ball, one of the reference's boxes for the others)
 checked on the host through rt_scene_layout: structure, coverage of the primitives, box enclosure, and that the stackless walk
 visits every primitive whose reference bounding box (src/*.jl bounding_box) the ray passes -- the walk may only cull
-what the reference's exact slab test (src/bounding_box.jl:20-67) culls too.  No GPU needed."""
+what the reference's exact slab test (src/bounding_box.jl:20-67) culls too.  The same for the second form of the tree of
+surfaces, the pair nodes that rt_extend_kernel walks with a stack (rt_scene_layout_pairs).  No GPU needed."""
 import numpy as np
 import pytest
 
