@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mpaths/s of the path-tracing loop on cu_cover2 (800x800, 1000 spp), the configuration
-BASELINE.json quotes, with the spp dimension sharded over N GPUs (one process per GPU) and the per-GPU
+the reference's headline metric is quoted on, with the spp dimension sharded over N GPUs (one process per GPU) and the per-GPU
 accumulators summed by one RCCL all-reduce.
 
   python bench.py --gpus 1 --steps K --warmup W
@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1000)
     ap.add_argument("--cpu-spp", type=int, default=24, help="pattern columns of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-other", action="store_true", help="skip the other BASELINE configurations (one frame each)")
+    ap.add_argument("--no-other", action="store_true", help="skip the other benchmark configurations of the reference (one frame each)")
     args = ap.parse_args()
 
     import numpy as np
@@ -184,7 +184,7 @@ def main():
         line["roofline"] = roofline
         line["cpu_baseline"] = cpu
         if world_size == 1 and not args.no_other and args.scene == "cu_cover2":
-            # the other configurations BASELINE.json names, one GPU each, second frame of a resident scene (buffers warm)
+            # the reference's other benchmark configurations, one GPU each, second frame of a resident scene (buffers warm)
             other = {}
             for key, spp in (("cover1", 500), ("teapot", 1000), ("cornell_box", 1000), ("cornell_smoke_box", 10000)):
                 w2, k2 = rt.get_scene(key, spp=spp)

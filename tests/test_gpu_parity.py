@@ -494,7 +494,7 @@ def test_device_output_stage_matches_host_quantisation(scenes):
 
 
 def test_full_size_cu_cover2_against_oracle_and_properties(scenes):
-    """BASELINE configuration at full resolution (800x800): a few pattern columns against the oracle bit for bit, and
+    """The headline configuration at full resolution (800x800): a few pattern columns against the oracle bit for bit, and
     size-independent properties at more columns: run-to-run determinism and column-additivity."""
     world, kw, dev, ref = scenes("cu_cover2")
     cam, bg = kw["camera"], kw["background"]
