@@ -103,7 +103,8 @@ int upload_nodes(rtScene* s) {
     // the stack (a lane pushes at most one entry per level)
     s->dev.pairs = s->d_pairs;
     s->dev.n_pairs = H.pairs_per_layout;
-    s->dev.use_pairs = (H.pairs_per_layout && depth <= RT_PAIR_STACK && !std::getenv("RT_AMD_NO_PAIRS")) ? 1u : 0u;
+    // (and when a record's byte offset fits 32 bits: 16 layouts of 32-byte records)
+    s->dev.use_pairs = (H.pairs_per_layout && H.pairs_per_layout < (1u << 23) && depth <= RT_PAIR_STACK && !std::getenv("RT_AMD_NO_PAIRS")) ? 1u : 0u;
     s->dev.nodes = s->d_nodes;
     s->dev.n_nodes = H.nodes_per_layout;
     s->dev.far_set = H.n_sets == 2 ? 8u * H.nodes_per_layout : 0u;

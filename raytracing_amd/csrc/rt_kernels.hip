@@ -1743,7 +1743,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
             do {
                 if (PAIRS && stepping) {
                     if (COUNT) { cnt.nodes += 2; cnt.node_waves += first_active_lane(); }
-                    const uint4* rec = S.pairs + ((size_t)node << 1);
+                    const uint4* rec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.pairs) + (node << 5)); // (32-bit offset: fewer than 2^27 records)
                     const uint4 qa = rec[0], qb = rec[1];
                     const uint32_t top = pair_stack[sp ? sp - 1u : 0u][threadIdx.x]; // (wanted only if this step ends a subtree)
                     bool hit2[2];
@@ -1765,8 +1765,14 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                     nq += (hit2[0] && leaf_a) ? 1u : 0u;
                     const bool go_a = hit2[0] && !leaf_a, go_b = hit2[1] && !leaf_b;
                     pair_stack[sp][threadIdx.x] = qb.w; // (sp <= depth of the record read < RT_PAIR_STACK)
-                    node = go_a ? qa.w : (go_b ? qb.w : (sp ? top : 0xFFFFFFFFu));
-                    sp = sp + ((go_a && go_b) ? 1u : 0u) - ((!go_a && !go_b && sp != 0u) ? 1u : 0u);
+                    {   // next record: the near child's, else the far child's, else the top of the stack, else none (all ones).
+                        // Written on lane masks so that it stays straight-line code.
+                        const uint32_t ga = go_a ? 0xFFFFFFFFu : 0u, gb = go_b ? 0xFFFFFFFFu : 0u, has = sp ? 0xFFFFFFFFu : 0u;
+                        uint32_t nxt = (has & top) | ~has;
+                        nxt = (gb & qb.w) | (~gb & nxt);
+                        node = (ga & qa.w) | (~ga & nxt);
+                        sp = sp + (ga & gb & 1u) - (~(ga | gb) & has & 1u);
+                    }
                 }
                 if (!PAIRS && stepping) {
                     if (COUNT) { cnt.nodes++; cnt.node_waves += first_active_lane(); }
