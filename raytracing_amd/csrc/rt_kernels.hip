@@ -1609,7 +1609,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
         }
         const bool fin = busy && nq == 0u && node == end;
         const bool wl = busy && nq != 0u;
-        const bool ws = busy && node != end && (PAIRS ? nq + 2u <= PAIR_LEAVES : nq < LEAF_QUEUE) && !(NESTED && nq != 0u && (q0 & RT_LEAF_INSTANCE));
+        const bool ws = busy && node != end && (PAIRS ? nq <= PAIR_LEAVES - 2u : nq < LEAF_QUEUE) && !(NESTED && nq != 0u && (q0 & RT_LEAF_INSTANCE));
         const uint32_t n_need = (uint32_t)__popcll(__ballot(!busy || fin));
         const uint32_t nl = (uint32_t)__popcll(__ballot(wl));
         const uint32_t ns = (uint32_t)__popcll(__ballot(ws));
@@ -1798,7 +1798,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                 }
                 // from the lane's state (the same test as `ws` above), each comparison voted on its own: the votes are
                 // then the comparisons' lane masks themselves, combined by scalar instructions
-                const bool more = node != end, room = PAIRS ? nq + 2u <= PAIR_LEAVES : nq < LEAF_QUEUE;
+                const bool more = node != end, room = PAIRS ? nq <= PAIR_LEAVES - 2u : nq < LEAF_QUEUE;
                 const bool enter = NESTED && nq != 0u && (q0 & RT_LEAF_INSTANCE);
                 stepping = busy && more && room && !enter;
                 n_step = (uint32_t)__popcll(m_busy & __builtin_amdgcn_ballot_w64(more) & __builtin_amdgcn_ballot_w64(room) &
