@@ -328,6 +328,82 @@ void rt_scene_desc_free(rtSceneDesc* desc);
  * *counter is the index of the next unused draw (768 or 256 values + 765 shuffle draws later). */
 int rt_perlin_generate(uint32_t seed, uint64_t* counter, int32_t vector, rtPerlin* out);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * F = Float64: render(Float64, ...) (main.jl:21,46).  The reference is generic in its element type F (Vec3{F},
+ * Ray{F}, Camera{F}, BVHNode{F}, ...; main.jl:21 takes it as its first argument); everything above is F = Float32,
+ * its default.  For Float64 the same records exist with double fields, and a second set of entry points takes
+ * them.  The device then walks the reference's own trees (the ones in the description, one per type group) with the
+ * reference's own box test in double, so results equal the CPU path's for Float64 bit for bit (random numbers: 53
+ * bits from two words of the same counter-based generator).  Image buffers are double: the memory order of a Julia
+ * Array{RGB{Float64},2}(H, W).  Unsupported nestings are the Float32 path's (RT_EUNSUPPORTED); in addition the trees
+ * may need at most 48 stack entries per walk (a tree of meshes: its two levels together), which holds for any tree the
+ * reference's median split builds over fewer than 2^40 objects. */
+typedef struct rtObject64 { int32_t kind, material, child, aux; double p[12]; } rtObject64;     /* as rtObject */
+typedef struct rtTransform64 { double xform[12], inv_xform[12], bbox[6]; } rtTransform64;       /* as rtTransform */
+typedef struct rtMaterial64 { int32_t type, texture; double fuzz, eta; } rtMaterial64;          /* as rtMaterial */
+typedef struct rtTexture64 { int32_t kind, a, b, pad; double color[3]; double scale; } rtTexture64; /* as rtTexture; a
+                                                                  checker's two textures must precede it in the table */
+typedef struct rtPerlin64 { double ranvec[256 * 3]; int32_t perm_x[256], perm_y[256], perm_z[256]; } rtPerlin64;
+typedef struct rtMesh64 {
+    int32_t n_vertices, n_triangles, n_materials, pad;
+    const double* vertices; /* 8 per vertex */
+    const int32_t* indices;
+    const int32_t* materials;
+    const int32_t* tri_ids;
+} rtMesh64;
+typedef struct rtBvh64 {
+    int32_t kind, n_objects;
+    const int32_t* objects;
+    int32_t n_nodes, pad;
+    const double* node_bounds;
+    const int32_t* node_left;
+    const int32_t* node_right;
+    const uint8_t* node_leaf;
+} rtBvh64;
+typedef struct rtSceneDesc64 {
+    int32_t n_objects;    const rtObject64* objects;
+    int32_t n_top;        const int32_t* top;
+    int32_t n_transforms; const rtTransform64* transforms;
+    int32_t n_materials;  const rtMaterial64* materials;
+    int32_t n_textures;   const rtTexture64* textures;
+    int32_t n_images;     const rtImage* images;
+    int32_t n_perlins;    const rtPerlin64* perlins;
+    int32_t n_meshes;     const rtMesh64* meshes;
+    int32_t n_groups;     const rtBvh64* groups;
+    int32_t n_buckets;    const rtBvh64* buckets;
+} rtSceneDesc64;
+typedef struct rtCamera64 { /* src/camera.jl:3-14 with F = Float64 */
+    double origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    double lens_radius, t0, t1;
+} rtCamera64;
+typedef struct rtScene64 rtScene64;
+
+/* rt_scene_create / rt_scene_destroy for a Float64 scene: validates and copies the description's tables and trees as
+ * they are (no device-side tree build: the walk is the reference's, see above). */
+int rt_scene_create_f64(const rtSceneDesc64* desc, int device, rtScene64** out);
+int rt_scene_destroy_f64(rtScene64* scene);
+/* draw!(img::CuArray{RGB{Float64}}, ...) (src/Ray_Tracing.jl:141-157): as rt_render, `out` receives 3*H*W doubles.
+ * stats: seconds and paths are filled, the counters stay 0.  flags are ignored. */
+int rt_render_f64(rtScene64* scene, const rtCamera64* camera, const double* pattern, int n, const double background[3],
+                  int width, int height, int max_depth, uint64_t seed, uint32_t flags, double* out, rtStats* stats);
+/* the two halves, as rt_render_accumulate / rt_finalize (d_accum, d_out: 3*H*W doubles in device memory) */
+int rt_render_accumulate_f64(rtScene64* scene, const rtCamera64* camera, const double* pattern, int n, int sample_first,
+                             int sample_stride, const double background[3], int width, int height, int max_depth,
+                             uint64_t seed, double* d_accum, void* stream);
+int rt_finalize_f64(rtScene64* scene, const double* d_accum, int n_total, int width, int height, double* d_out, void* stream);
+/* parity hooks, as rt_trace_rays / rt_trace_paths */
+int rt_trace_rays_f64(rtScene64* scene, const double* rays, int n, double t_min, double t_max, uint64_t seed,
+                      int32_t* prim_id, int32_t* sub_id, double* t, double* normal, double* uv, uint8_t* front);
+int rt_trace_paths_f64(rtScene64* scene, const rtCamera64* camera, const double* pattern, int n, const double background[3],
+                       int width, int height, int max_depth, uint64_t seed, const int32_t* ids, int n_paths, double* radiance);
+/* build_bvh (src/BVH.jl:65-109, src/mesh.jl:217-305) over Float64 boxes and vertices, as rt_bvh_build / rt_bvh_build_meshes */
+int rt_bvh_build_f64(int n, const double* object_bounds, int32_t* order, double* node_bounds, int32_t* node_left,
+                     int32_t* node_right, uint8_t* node_leaf);
+int rt_bvh_build_meshes_f64(int n_meshes, const int32_t* n_vertices, const double* const* vertices,
+                            const int32_t* n_triangles, int32_t* const* indices, int32_t* const* tri_ids,
+                            int32_t* mesh_order, double* node_bounds, int32_t* node_left, int32_t* node_right,
+                            uint8_t* node_leaf);
+
 #ifdef __cplusplus
 }
 #endif

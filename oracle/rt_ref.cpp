@@ -2,7 +2,7 @@
  * rt_ref.cpp -- CPU ORACLE (test infrastructure only, see rt_ref.h).
  *
  * Restates the CPU path of rafaellg79/raytracing in plain C++: same formulas, same
- * comparison operators, same tie-breaks, same evaluation order of every float
+ * comparison operators, same tie-breaks, same evaluation order of every real
  * expression (Julia evaluates a*b + c*d + e*f left to right, no FMA contraction;
  * build with -ffp-contract=off).  Citations are file:line in the reference tree.
  *
@@ -25,41 +25,44 @@
 
 namespace {
 
-const float INF = std::numeric_limits<float>::infinity();
+typedef ref_real real;      /* float, or double in the Float64 build (-DREF_F64) */
+#define R(x) ((real)(x))    /* a literal of the element type: F(x) in the reference */
+
+const real INF = std::numeric_limits<real>::infinity();
 thread_local std::string g_err;
 
 /* ------------------------------------------------------------------ vec3.jl */
 struct V3 {
-    float x, y, z;
+    real x, y, z;
 };
-inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
-inline V3 v3(float s) { return V3{s, s, s}; }
+inline V3 v3(real x, real y, real z) { return V3{x, y, z}; }
+inline V3 v3(real s) { return V3{s, s, s}; }
 inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }    /* vec3.jl:18 */
 inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }    /* vec3.jl:19 */
 inline V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }    /* vec3.jl:20 */
 inline V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }                          /* vec3.jl:25 */
-inline V3 operator+(V3 a, float b) { return v3(a.x + b, a.y + b, a.z + b); }        /* vec3.jl:28 */
-inline V3 operator-(V3 a, float b) { return v3(a.x - b, a.y - b, a.z - b); }        /* vec3.jl:29 */
-inline V3 operator*(V3 a, float b) { return v3(a.x * b, a.y * b, a.z * b); }        /* vec3.jl:30 */
-inline V3 operator*(float a, V3 b) { return v3(a * b.x, a * b.y, a * b.z); }        /* vec3.jl:35 */
-inline V3 div_real(V3 a, float b) { return a * (1.0f / b); }                        /* vec3.jl:31  a * F(1/b) */
-inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          /* vec3.jl:46 */
+inline V3 operator+(V3 a, real b) { return v3(a.x + b, a.y + b, a.z + b); }        /* vec3.jl:28 */
+inline V3 operator-(V3 a, real b) { return v3(a.x - b, a.y - b, a.z - b); }        /* vec3.jl:29 */
+inline V3 operator*(V3 a, real b) { return v3(a.x * b, a.y * b, a.z * b); }        /* vec3.jl:30 */
+inline V3 operator*(real a, V3 b) { return v3(a * b.x, a * b.y, a * b.z); }        /* vec3.jl:35 */
+inline V3 div_real(V3 a, real b) { return a * (R(1.0) / b); }                        /* vec3.jl:31  a * F(1/b) */
+inline real dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          /* vec3.jl:46 */
 inline V3 cross(V3 a, V3 b) {                                                       /* vec3.jl:49 */
     return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-inline float length(V3 a) { return sqrtf(dot(a, a)); }                              /* vec3.jl:52 */
+inline real length(V3 a) { return std::sqrt(dot(a, a)); }                              /* vec3.jl:52 */
 inline V3 normalize(V3 a) { return div_real(a, length(a)); }                        /* vec3.jl:57 */
 /* vec3.jl:62-64: isapprox(x, 0) with default tolerances holds only for x == 0 */
-inline bool almost_zero(V3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
-inline V3 vmin(V3 a, V3 b) { return v3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
-inline V3 vmax(V3 a, V3 b) { return v3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
-inline float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+inline bool almost_zero(V3 a) { return a.x == R(0.0) && a.y == R(0.0) && a.z == R(0.0); }
+inline V3 vmin(V3 a, V3 b) { return v3(std::fmin(a.x, b.x), std::fmin(a.y, b.y), std::fmin(a.z, b.z)); }
+inline V3 vmax(V3 a, V3 b) { return v3(std::fmax(a.x, b.x), std::fmax(a.y, b.y), std::fmax(a.z, b.z)); }
+inline real comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
 struct Ray { /* ray.jl:3 */
     V3 o, d;
-    float time;
+    real time;
 };
-inline V3 at(const Ray& r, float t) { return r.o + r.d * t; } /* ray.jl:15 */
+inline V3 at(const Ray& r, real t) { return r.o + r.d * t; } /* ray.jl:15 */
 
 struct AABB { /* bounding_box.jl:4 */
     V3 mn, mx;
@@ -163,7 +166,111 @@ inline void pcg4d(uint32_t v[4]) {
     for (int i = 0; i < 4; ++i) v[i] ^= v[i] >> 16;
     v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
 }
+
+
+/* ---- the same four routines at double accuracy, for the Float64 build (render(Float64, ...), main.jl:21,46):
+ * IEEE basic operations only, so that the kernels' copies give the same bits. */
+inline double det_logd(double x) { /* x in (0,1): argument reduction x = 2^k * m, m in [sqrt(1/2), sqrt(2)); atanh series */
+    if (x == 0.0) return -std::numeric_limits<double>::infinity();
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t bits; memcpy(&bits, &x, 8);
+    uint32_t hx = (uint32_t)(bits >> 32);
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    int k = (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    bits = ((uint64_t)hx << 32) | (bits & 0xffffffffu);
+    double m; memcpy(&m, &bits, 8);
+    double f = m - 1.0;
+    double hfsq = 0.5 * f * f;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    double R = t2 + t1;
+    double dk = (double)k;
+    return (((s * (hfsq + R) + dk * ln2_lo) - hfsq) + f) + dk * ln2_hi;
+}
+inline double det_sind(double x) { /* quadrant by a two-part pi/2 (exact product for |x| < 1.6e6), then the two kernels */
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_1 = 1.57079632673412561417e+00, PIO2_1T = 6.07710050650619224932e-11;
+    double n = floor(x * TWO_OVER_PI + 0.5);
+    double r = (x - n * PIO2_1) - n * PIO2_1T;
+    long long q = (long long)n;
+    double z = r * r;
+    double sn, cs;
+    {
+        const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                     S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+        double p = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+        sn = r + (r * z) * (S1 + z * p);
+    }
+    {
+        const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                     C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+        double p = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+        cs = 1.0 - (0.5 * z - z * p);
+    }
+    switch ((int)(q & 3)) {
+        case 0: return sn;
+        case 1: return cs;
+        case 2: return -sn;
+        default: return -cs;
+    }
+}
+inline double det_atan01_full(double z) { /* atan(z), z in [0,1]: three half-angle reductions, then the odd series */
+    z = z / (1.0 + sqrt(1.0 + z * z));
+    z = z / (1.0 + sqrt(1.0 + z * z));
+    z = z / (1.0 + sqrt(1.0 + z * z));
+    double w = z * z;
+    double p = 1.0 / 19.0;
+    p = 1.0 / 17.0 - w * p;
+    p = 1.0 / 15.0 - w * p;
+    p = 1.0 / 13.0 - w * p;
+    p = 1.0 / 11.0 - w * p;
+    p = 1.0 / 9.0 - w * p;
+    p = 1.0 / 7.0 - w * p;
+    p = 1.0 / 5.0 - w * p;
+    p = 1.0 / 3.0 - w * p;
+    p = 1.0 - w * p;
+    return 8.0 * (z * p);
+}
+inline double det_atan2_full(double y, double x) {
+    const double PI = 3.14159265358979323846;
+    double ax = fabs(x), ay = fabs(y);
+    double a;
+    if (ax == 0.0 && ay == 0.0) a = 0.0;
+    else if (ax >= ay) a = det_atan01_full(ay / ax);
+    else a = 0.5 * PI - det_atan01_full(ax / ay);
+    if (std::signbit(x)) a = PI - a;
+    if (std::signbit(y)) a = -a;
+    return a;
+}
+inline double det_acosd(double c) {
+    double s = sqrt((1.0 - c) * (1.0 + c));
+    return det_atan2_full(s, c);
+}
+
+/* the element type of the build picks its routines and the width of its random numbers */
+#ifdef REF_F64
+inline double det_log(double x) { return det_logd(x); }
+inline double det_sin(double x) { return det_sind(x); }
+inline double det_acos(double x) { return det_acosd(x); }
+inline double det_atan2(double y, double x) { return det_atan2_full(y, x); }
+#else
+inline float det_log(float x) { return det_logf(x); }
+inline float det_sin(float x) { return det_sinf(x); }
+inline float det_acos(float x) { return det_acosf(x); }
+inline float det_atan2(float y, float x) { return det_atan2f(y, x); }
+#endif
 inline float u32_to_01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+/* 53 bits from two words: 27 from the first, 26 from the second */
+inline double u64_to_01(uint32_t hi, uint32_t lo) {
+    return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * (1.0 / 9007199254740992.0);
+}
 
 enum { PURPOSE_TRIAL = 0, PURPOSE_SCALAR = 1, PURPOSE_MEDIUM = 2 };
 enum { CAMERA_BOUNCE = 63 };
@@ -179,10 +286,20 @@ struct Ctx { /* identifies the random stream of the path being traced */
     uint32_t pixel = 0, sample = 0, seed32 = 0, bounce = 0;
     Stats* st = nullptr;
     std::vector<Ray>* ray_log = nullptr; /* when set, trace() records every ray it casts */
-    void draw(uint32_t purpose, uint32_t k, float out[4]) const {
+    void draw(uint32_t purpose, uint32_t k, real out[4]) const {
+#ifdef REF_F64
+        /* rand(Float64): 53 bits each, two words of the generator per number, two hashes per draw */
+        uint32_t a[4] = {pixel, sample, rng_counter(bounce, purpose, 2 * k), seed32};
+        uint32_t b[4] = {pixel, sample, rng_counter(bounce, purpose, 2 * k + 1), seed32};
+        pcg4d(a);
+        pcg4d(b);
+        out[0] = u64_to_01(a[0], a[1]); out[1] = u64_to_01(a[2], a[3]);
+        out[2] = u64_to_01(b[0], b[1]); out[3] = u64_to_01(b[2], b[3]);
+#else
         uint32_t v[4] = {pixel, sample, rng_counter(bounce, purpose, k), seed32};
         pcg4d(v);
         for (int i = 0; i < 4; ++i) out[i] = u32_to_01(v[i]);
+#endif
     }
 };
 inline uint32_t fold_seed(uint64_t seed) { return (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u); }
@@ -190,35 +307,35 @@ inline uint32_t fold_seed(uint64_t seed) { return (uint32_t)seed ^ ((uint32_t)(s
 /* vec3.jl:87-94: rejection sampling, 3 rands per trial in x,y,z order, rand*(max-min)+min */
 V3 random_in_unit_sphere(const Ctx& c) {
     for (uint32_t k = 0;; ++k) {
-        float r[4];
+        real r[4];
         c.draw(PURPOSE_TRIAL, k, r);
-        V3 p = v3(r[0] * 2.0f + -1.0f, r[1] * 2.0f + -1.0f, r[2] * 2.0f + -1.0f);
-        if (!(dot(p, p) > 1.0f)) return p;
+        V3 p = v3(r[0] * R(2.0) + -R(1.0), r[1] * R(2.0) + -R(1.0), r[2] * R(2.0) + -R(1.0));
+        if (!(dot(p, p) > R(1.0))) return p;
     }
 }
 /* vec3.jl:96-105 */
 V3 random_in_unit_disk(const Ctx& c) {
     for (uint32_t k = 0;; ++k) {
-        float r[4];
+        real r[4];
         c.draw(PURPOSE_TRIAL, k, r);
-        V3 p = v3(r[0] * 2.0f - 1.0f, r[1] * 2.0f - 1.0f, 0.0f);
-        if (!(dot(p, p) > 1.0f)) return p;
+        V3 p = v3(r[0] * R(2.0) - R(1.0), r[1] * R(2.0) - R(1.0), R(0.0));
+        if (!(dot(p, p) > R(1.0))) return p;
     }
 }
-float rand_scalar(const Ctx& c) {
-    float r[4];
+real rand_scalar(const Ctx& c) {
+    real r[4];
     c.draw(PURPOSE_SCALAR, 0, r);
     return r[0];
 }
 
 /* ------------------------------------------------------------ hit_record.jl */
 struct Hit {
-    float t = INF;
+    real t = INF;
     V3 p = {INF, INF, INF};
     V3 n = {0, 0, 0};
     int material = -1;
     bool front = false;
-    float u = 0, v = 0;
+    real u = 0, v = 0;
     int prim = -1; /* position in the world vector */
     int sub = 0;   /* box side / triangle / nested object */
 };
@@ -235,7 +352,7 @@ struct Tree { /* BVH.jl:12-16 */
     std::vector<int> objects;  /* object indices, permuted in place by the build */
 };
 struct MeshData {
-    std::vector<float> vertices;
+    std::vector<real> vertices;
     std::vector<int> indices; /* 4 x n, permuted by the build (mesh.jl:237) */
     std::vector<int> order;   /* original triangle id of each column */
     std::vector<int> materials;
@@ -272,14 +389,14 @@ AABB bounding_box(const ref_scene& S, int oi);
 AABB mesh_bbox(const MeshData& m, const int* vids, int count) { /* mesh.jl:45-49 */
     V3 mn = v3(INF), mx = v3(-INF);
     for (int k = 0; k < count; ++k) {
-        const float* v = &m.vertices[8 * vids[k]];
+        const real* v = &m.vertices[8 * vids[k]];
         mn = vmin(mn, v3(v[0], v[1], v[2]));
         mx = vmax(mx, v3(v[0], v[1], v[2]));
     }
     /* Vec3{Float32} - 0.0001 (Float64 literal): computed in double, narrowed on construction */
     AABB b;
-    b.mn = v3((float)((double)mn.x - 0.0001), (float)((double)mn.y - 0.0001), (float)((double)mn.z - 0.0001));
-    b.mx = v3((float)((double)mx.x + 0.0001), (float)((double)mx.y + 0.0001), (float)((double)mx.z + 0.0001));
+    b.mn = v3((real)((double)mn.x - 0.0001), (real)((double)mn.y - 0.0001), (real)((double)mn.z - 0.0001));
+    b.mx = v3((real)((double)mx.x + 0.0001), (real)((double)mx.y + 0.0001), (real)((double)mx.z + 0.0001));
     return b;
 }
 AABB mesh_bbox_all(const MeshData& m) {
@@ -296,28 +413,28 @@ AABB mesh_bbox_range(const MeshData& m, int left, int right) { /* indices[1:3, l
 
 AABB bounding_box(const ref_scene& S, int oi) {
     const refObject& o = S.objects[oi];
-    const float* p = o.p;
+    const real* p = o.p;
     switch (o.kind) {
         case REF_SPHERE: { /* sphere.jl:32-34 */
             V3 c = v3(p[0], p[1], p[2]);
-            float r = fabsf(p[3]);
+            real r = std::fabs(p[3]);
             return AABB{c - r, c + r};
         }
         case REF_MOVING_SPHERE: { /* sphere.jl:36-38 */
             V3 c0 = v3(p[0], p[1], p[2]), c1 = v3(p[4], p[5], p[6]);
-            float r = fabsf(p[8]);
+            real r = std::fabs(p[8]);
             return AABB{vmin(c0 - r, c1 - r), vmax(c0 + r, c1 + r)};
         }
         case REF_XY_RECT: /* aarect.jl:37-39 */
-            return AABB{v3(p[0], p[2], p[4] - 0.0001f), v3(p[1], p[3], p[4] + 0.0001f)};
+            return AABB{v3(p[0], p[2], p[4] - R(0.0001)), v3(p[1], p[3], p[4] + R(0.0001))};
         case REF_XZ_RECT: /* aarect.jl:41-43 */
-            return AABB{v3(p[0], p[4] - 0.0001f, p[2]), v3(p[1], p[4] + 0.0001f, p[3])};
+            return AABB{v3(p[0], p[4] - R(0.0001), p[2]), v3(p[1], p[4] + R(0.0001), p[3])};
         case REF_YZ_RECT: /* aarect.jl:45-47 */
-            return AABB{v3(p[4] - 0.0001f, p[0], p[2]), v3(p[4] + 0.0001f, p[1], p[3])};
+            return AABB{v3(p[4] - R(0.0001), p[0], p[2]), v3(p[4] + R(0.0001), p[1], p[3])};
         case REF_BOX: /* box.jl:85-87 */
             return AABB{v3(p[0], p[1], p[2]), v3(p[3], p[4], p[5])};
         case REF_TRANSFORM: { /* transform.jl:100-102 (cached at construction, :47-63) */
-            const float* b = S.transforms[o.aux].bbox;
+            const real* b = S.transforms[o.aux].bbox;
             return AABB{v3(b[0], b[1], b[2]), v3(b[3], b[4], b[5])};
         }
         case REF_CONSTANT_MEDIUM: /* constant_medium.jl:25-27 */
@@ -343,7 +460,7 @@ AABB surrounding_box(const ref_scene& S, const std::vector<int>& objs, int left,
 int longest_axis(const AABB& box) { /* BVH.jl:76-77: findmax returns the first maximum */
     V3 e = box.mx - box.mn;
     int axis = 0;
-    float best = e.x;
+    real best = e.x;
     if (e.y > best) { best = e.y; axis = 1; }
     if (e.z > best) { best = e.z; axis = 2; }
     return axis;
@@ -361,11 +478,11 @@ int build_bvh(const ref_scene& S, Tree& tree, int node_id, int left, int right) 
     AABB box = surrounding_box(S, tree.objects, left, right);
     int axis = longest_axis(box);
     /* sort!(view; by=bounding_box, lt = a.min[axis] < b.min[axis]) -- stable merge sort */
-    std::vector<std::pair<float, int>> keyed;
+    std::vector<std::pair<real, int>> keyed;
     for (int i = left; i <= right; ++i)
         keyed.push_back({comp(bounding_box(S, tree.objects[i - 1]).mn, axis), tree.objects[i - 1]});
     std::stable_sort(keyed.begin(), keyed.end(),
-                     [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first < b.first; });
+                     [](const std::pair<real, int>& a, const std::pair<real, int>& b) { return a.first < b.first; });
     for (int i = left; i <= right; ++i) tree.objects[i - 1] = keyed[i - left].second;
 
     int mid = (left + right) / 2;
@@ -400,7 +517,7 @@ int build_mesh_tris(ref_scene& S, Tree& tree, MeshData& m, int node_id, int left
     AABB box = mesh_bbox_range(m, left, right);
     int axis = longest_axis(box);
     /* sortslices(view indices[:, left:right]; dims=2, by=bbox of the column, lt=min[axis] <) -- stable */
-    struct Col { float key; int idx[4]; int order; };
+    struct Col { real key; int idx[4]; int order; };
     std::vector<Col> cols;
     for (int c = left; c <= right; ++c) {
         Col col;
@@ -439,11 +556,11 @@ int build_mesh_level(ref_scene& S, Tree& tree, int node_id, int left, int right)
     }
     AABB box = surrounding_box(S, tree.objects, left, right);
     int axis = longest_axis(box);
-    std::vector<std::pair<float, int>> keyed;
+    std::vector<std::pair<real, int>> keyed;
     for (int i = left; i <= right; ++i)
         keyed.push_back({comp(bounding_box(S, tree.objects[i - 1]).mn, axis), tree.objects[i - 1]});
     std::stable_sort(keyed.begin(), keyed.end(),
-                     [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first < b.first; });
+                     [](const std::pair<real, int>& a, const std::pair<real, int>& b) { return a.first < b.first; });
     for (int i = left; i <= right; ++i) tree.objects[i - 1] = keyed[i - left].second;
     int mid = (left + right) / 2;
     int ln = build_mesh_level(S, tree, node_id * 2, left, mid);
@@ -462,9 +579,9 @@ void build_mesh_tree(ref_scene& S, Tree& tree) { /* mesh.jl:294-305 */
 }
 
 /* ------------------------------------------- bounding_box.jl:20-67 (CPU slab) */
-bool hit_aabb(const AABB& b, const Ray& r, float t_min, float t_max) {
-    float tmin = (b.mn.x - r.o.x) / r.d.x;
-    float tmax = (b.mx.x - r.o.x) / r.d.x;
+bool hit_aabb(const AABB& b, const Ray& r, real t_min, real t_max) {
+    real tmin = (b.mn.x - r.o.x) / r.d.x;
+    real tmax = (b.mx.x - r.o.x) / r.d.x;
     if (tmin > tmax) std::swap(tmin, tmax);
     if (tmax < t_max) t_max = tmax;
     if (tmin > t_min) t_min = tmin;
@@ -487,31 +604,31 @@ bool hit_aabb(const AABB& b, const Ray& r, float t_min, float t_max) {
 }
 
 /* -------------------------------------------------------------- primitives */
-Hit hit_object(const ref_scene& S, int oi, const Ray& r, float t_min, float t_max, const Ctx& c);
-Hit hit_tree(const ref_scene& S, const Tree& tree, const Ray& r, float t_min, float t_max, const Ctx& c, bool nested);
+Hit hit_object(const ref_scene& S, int oi, const Ray& r, real t_min, real t_max, const Ctx& c);
+Hit hit_tree(const ref_scene& S, const Tree& tree, const Ray& r, real t_min, real t_max, const Ctx& c, bool nested);
 
 /* sphere.jl:104-108 */
-inline void get_sphere_uv(V3 p, float& u, float& v) {
-    const float PI_F = 3.14159265358979323846f;
-    const float TWO_PI_F = (float)(2.0 * 3.14159265358979323846);
-    float cy = -p.y;
-    cy = cy < -1.0f ? -1.0f : (cy > 1.0f ? 1.0f : cy);
-    float theta = det_acosf(cy);
-    float phi = det_atan2f(-p.z, p.x) + PI_F;
+inline void get_sphere_uv(V3 p, real& u, real& v) {
+    const real PI_F = R(3.14159265358979323846);
+    const real TWO_PI_F = (real)(2.0 * 3.14159265358979323846);
+    real cy = -p.y;
+    cy = cy < -R(1.0) ? -R(1.0) : (cy > R(1.0) ? R(1.0) : cy);
+    real theta = det_acos(cy);
+    real phi = det_atan2(-p.z, p.x) + PI_F;
     u = phi / TWO_PI_F;
     v = theta / PI_F;
 }
 
 /* sphere.jl:45-72 and :74-102 (centre passed in) */
-Hit hit_sphere(V3 center, float radius, int material, const Ray& r, float t_min, float t_max) {
+Hit hit_sphere(V3 center, real radius, int material, const Ray& r, real t_min, real t_max) {
     V3 oc = r.o - center;
-    float a = dot(r.d, r.d);
-    float half_b = dot(oc, r.d);
-    float c = dot(oc, oc) - radius * radius;
-    float discriminant = half_b * half_b - a * c;
-    if (discriminant < 0.0f) return Hit();
-    float sqrtd = sqrtf(discriminant);
-    float root = (-half_b - sqrtd);
+    real a = dot(r.d, r.d);
+    real half_b = dot(oc, r.d);
+    real c = dot(oc, oc) - radius * radius;
+    real discriminant = half_b * half_b - a * c;
+    if (discriminant < R(0.0)) return Hit();
+    real sqrtd = std::sqrt(discriminant);
+    real root = (-half_b - sqrtd);
     if (root < t_min * a || t_max * a < root) {
         root = (-half_b + sqrtd);
         if (root < t_min * a || t_max * a < root) return Hit();
@@ -521,24 +638,24 @@ Hit hit_sphere(V3 center, float radius, int material, const Ray& r, float t_min,
     h.t = root;
     h.p = at(r, root);
     V3 normal = div_real(h.p - center, radius);
-    h.front = dot(r.d, normal) < 0.0f;
+    h.front = dot(r.d, normal) < R(0.0);
     get_sphere_uv(normal, h.u, h.v);
-    h.n = (float)(-1 + ((int)h.front << 1)) * normal;
+    h.n = (real)(-1 + ((int)h.front << 1)) * normal;
     h.material = material;
     return h;
 }
 
 /* aarect.jl:49-119; axis = the constant axis (2: xy_rect, 1: xz_rect, 0: yz_rect) */
-Hit hit_rect(int axis, float a0, float a1, float b0, float b1, float k, int material, const Ray& r, float t_min,
-             float t_max) {
-    float ok, dk, oa, da, ob, db;
+Hit hit_rect(int axis, real a0, real a1, real b0, real b1, real k, int material, const Ray& r, real t_min,
+             real t_max) {
+    real ok, dk, oa, da, ob, db;
     if (axis == 2) { ok = r.o.z; dk = r.d.z; oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
     else if (axis == 1) { ok = r.o.y; dk = r.d.y; oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
     else { ok = r.o.x; dk = r.d.x; oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; }
-    float t = (k - ok) / dk;
+    real t = (k - ok) / dk;
     if (t < t_min || t_max < t) return Hit();
-    float a = oa + t * da;
-    float b = ob + t * db;
+    real a = oa + t * da;
+    real b = ob + t * db;
     if (a < a0 || a1 < a || b < b0 || b1 < b) return Hit();
     Hit h;
     h.t = t;
@@ -547,16 +664,16 @@ Hit hit_rect(int axis, float a0, float a1, float b0, float b1, float k, int mate
     else h.p = v3(k, a, b);
     /* aarect.jl:97-119: dot(direction, +axis) < 0 */
     V3 normal = axis == 2 ? v3(0, 0, 1) : (axis == 1 ? v3(0, 1, 0) : v3(1, 0, 0));
-    h.front = dot(r.d, normal) < 0.0f;
+    h.front = dot(r.d, normal) < R(0.0);
     h.u = (a - a0) / (a1 - a0);
     h.v = (b - b0) / (b1 - b0);
-    h.n = (float)(-1 + 2 * (int)h.front) * normal;
+    h.n = (real)(-1 + 2 * (int)h.front) * normal;
     h.material = material;
     return h;
 }
 
 /* box.jl:9-24 (side order) and :43-83 */
-Hit hit_box(const float* p, int material, const Ray& r, float t_min, float t_max) {
+Hit hit_box(const real* p, int material, const Ray& r, real t_min, real t_max) {
     V3 p0 = v3(p[0], p[1], p[2]), p1 = v3(p[3], p[4], p[5]);
     Hit closest;
     for (int s = 0; s < 6; ++s) {
@@ -579,59 +696,59 @@ Hit hit_box(const float* p, int material, const Ray& r, float t_min, float t_max
 }
 
 /* transform.jl:76-98 */
-inline V3 apply_point(const float* T, V3 v) {
+inline V3 apply_point(const real* T, V3 v) {
     return v3(T[0] * v.x + T[3] * v.y + T[6] * v.z + T[9], T[1] * v.x + T[4] * v.y + T[7] * v.z + T[10],
               T[2] * v.x + T[5] * v.y + T[8] * v.z + T[11]);
 }
-inline V3 apply_vec(const float* T, V3 v) {
+inline V3 apply_vec(const real* T, V3 v) {
     return v3(T[0] * v.x + T[3] * v.y + T[6] * v.z, T[1] * v.x + T[4] * v.y + T[7] * v.z,
               T[2] * v.x + T[5] * v.y + T[8] * v.z);
 }
 
 /* triangle.jl:73-91 */
-float hit_triangle_geom(V3 v1, V3 v2, V3 v3_, const Ray& r, float t_min, float t_max, V3& normal, float& u, float& v) {
+real hit_triangle_geom(V3 v1, V3 v2, V3 v3_, const Ray& r, real t_min, real t_max, V3& normal, real& u, real& v) {
     V3 e1 = v2 - v1;
     V3 e2 = v3_ - v1;
     V3 origin_v1 = v1 - r.o;
     normal = cross(e1, e2);
     V3 s = cross(origin_v1, r.d);
-    float c = 1.0f / dot(normal, r.d);
+    real c = R(1.0) / dot(normal, r.d);
     u = dot(s, e2) * c;
     v = dot(s, e1) * -c;
-    float t = dot(normal, origin_v1) * c;
-    if (u < 0.0f || v < 0.0f || u + v > 1.0f || t < t_min || t_max < t) {
-        u = -1.0f; v = -1.0f;
+    real t = dot(normal, origin_v1) * c;
+    if (u < R(0.0) || v < R(0.0) || u + v > R(1.0) || t < t_min || t_max < t) {
+        u = -R(1.0); v = -R(1.0);
         return INF;
     }
     return t;
 }
 /* mesh.jl:53-59 + triangle.jl:95-121 */
-Hit hit_mesh_triangle(const MeshData& m, int col /*1-based*/, const Ray& r, float t_min, float t_max) {
+Hit hit_mesh_triangle(const MeshData& m, int col /*1-based*/, const Ray& r, real t_min, real t_max) {
     const int* id = &m.indices[4 * (col - 1)];
-    const float* a = &m.vertices[8 * id[0]];
-    const float* b = &m.vertices[8 * id[1]];
-    const float* cc = &m.vertices[8 * id[2]];
+    const real* a = &m.vertices[8 * id[0]];
+    const real* b = &m.vertices[8 * id[1]];
+    const real* cc = &m.vertices[8 * id[2]];
     V3 normal;
-    float u, v;
-    float t = hit_triangle_geom(v3(a[0], a[1], a[2]), v3(b[0], b[1], b[2]), v3(cc[0], cc[1], cc[2]), r, t_min, t_max,
+    real u, v;
+    real t = hit_triangle_geom(v3(a[0], a[1], a[2]), v3(b[0], b[1], b[2]), v3(cc[0], cc[1], cc[2]), r, t_min, t_max,
                                 normal, u, v);
     if (t == INF) return Hit();
     /* get_triangle_vertex_at_uv: v1*w + v2*u + v3*v on every Vertex field (vertex.jl:20-25) */
-    float w = 1.0f - u - v;
+    real w = R(1.0) - u - v;
     V3 vn = (v3(a[3], a[4], a[5]) * w + v3(b[3], b[4], b[5]) * u) + v3(cc[3], cc[4], cc[5]) * v;
-    float vu = (a[6] * w + b[6] * u) + cc[6] * v;
-    float vv = (a[7] * w + b[7] * u) + cc[7] * v;
+    real vu = (a[6] * w + b[6] * u) + cc[6] * v;
+    real vv = (a[7] * w + b[7] * u) + cc[7] * v;
     /* triangle.jl:110-115: the flag is true when the interpolated normal is exactly zero, so meshes that
      * carry normals are shaded with the geometric normal and meshes without get a zero (-> NaN) normal */
     bool normal_flag = almost_zero(vn);
-    bool uv_flag = vu >= 0.0f && vv >= 0.0f;
+    bool uv_flag = vu >= R(0.0) && vv >= R(0.0);
     if (normal_flag) normal = vn;
     if (uv_flag) { u = vu; v = vv; }
     Hit h;
     h.t = t;
     h.p = at(r, t);
-    h.front = dot(r.d, normal) < 0.0f;
-    h.n = (float)(-1 + ((int)h.front << 1)) * normalize(normal);
+    h.front = dot(r.d, normal) < R(0.0);
+    h.n = (real)(-1 + ((int)h.front << 1)) * normalize(normal);
     h.material = m.materials[id[3]];
     h.u = u; h.v = v;
     h.sub = m.order[col - 1];
@@ -639,21 +756,21 @@ Hit hit_mesh_triangle(const MeshData& m, int col /*1-based*/, const Ray& r, floa
 }
 
 /* constant_medium.jl:29-65 */
-Hit hit_medium(const ref_scene& S, int oi, const Ray& r, float t_min, float t_max, const Ctx& c) {
+Hit hit_medium(const ref_scene& S, int oi, const Ray& r, real t_min, real t_max, const Ctx& c) {
     const refObject& o = S.objects[oi];
-    float t1 = hit_object(S, o.child, r, -INF, INF, c).t;
+    real t1 = hit_object(S, o.child, r, -INF, INF, c).t;
     if (t1 == INF) return Hit();
-    float t2 = hit_object(S, o.child, r, t1 + 0.0001f, INF, c).t;
+    real t2 = hit_object(S, o.child, r, t1 + R(0.0001), INF, c).t;
     if (t2 == INF) return Hit();
     if (t1 < t_min) t1 = t_min;
     if (t2 > t_max) t2 = t_max;
     if (t1 >= t2) return Hit();
-    if (t1 < 0.0f) t1 = 0.0f;
-    float ray_length = length(r.d);
-    float distance_inside_boundary = (t2 - t1) * ray_length;
-    float rnd[4];
+    if (t1 < R(0.0)) t1 = R(0.0);
+    real ray_length = length(r.d);
+    real distance_inside_boundary = (t2 - t1) * ray_length;
+    real rnd[4];
     c.draw(PURPOSE_MEDIUM, (uint32_t)oi, rnd);
-    float hit_distance = o.p[0] * det_logf(rnd[0]);
+    real hit_distance = o.p[0] * det_log(rnd[0]);
     if (hit_distance > distance_inside_boundary) return Hit();
     Hit h;
     h.t = t1 + hit_distance / ray_length;
@@ -665,10 +782,10 @@ Hit hit_medium(const ref_scene& S, int oi, const Ray& r, float t_min, float t_ma
     return h;
 }
 
-Hit hit_object(const ref_scene& S, int oi, const Ray& r, float t_min, float t_max, const Ctx& c) {
+Hit hit_object(const ref_scene& S, int oi, const Ray& r, real t_min, real t_max, const Ctx& c) {
     const refObject& o = S.objects[oi];
     if (c.st) c.st->prim_tests[o.kind]++;
-    const float* p = o.p;
+    const real* p = o.p;
     switch (o.kind) {
         case REF_SPHERE:
             return hit_sphere(v3(p[0], p[1], p[2]), p[3], o.material, r, t_min, t_max);
@@ -706,7 +823,7 @@ Hit hit_object(const ref_scene& S, int oi, const Ray& r, float t_min, float t_ma
 }
 
 /* BVH.jl:22-53 */
-Hit hit_tree(const ref_scene& S, const Tree& tree, const Ray& r, float t_min, float t_max, const Ctx& c, bool nested) {
+Hit hit_tree(const ref_scene& S, const Tree& tree, const Ray& r, real t_min, real t_max, const Ctx& c, bool nested) {
     if (tree.nodes.empty()) return Hit();
     std::vector<int> next(64);
     int n = 1;
@@ -720,7 +837,7 @@ Hit hit_tree(const ref_scene& S, const Tree& tree, const Ray& r, float t_min, fl
         if (node.leaf) {
             /* hittable.jl:21-31 list hit over objects[left:right] (a single object) */
             Hit lh;
-            float tm = t_max;
+            real tm = t_max;
             for (int i = node.left; i <= node.right; ++i) {
                 int oi = tree.objects[i - 1];
                 Hit h = hit_object(S, oi, r, t_min, tm, c);
@@ -741,7 +858,7 @@ Hit hit_tree(const ref_scene& S, const Tree& tree, const Ray& r, float t_min, fl
 }
 
 /* mesh.jl:115-163 (CPU: t_max is NOT narrowed) */
-Hit hit_mesh_tree(const ref_scene& S, const Tree& tree, const Ray& r, float t_min, float t_max, const Ctx& c) {
+Hit hit_mesh_tree(const ref_scene& S, const Tree& tree, const Ray& r, real t_min, real t_max, const Ctx& c) {
     if (tree.nodes.empty()) return Hit();
     std::vector<int> next(64);
     int n = 1;
@@ -768,7 +885,7 @@ Hit hit_mesh_tree(const ref_scene& S, const Tree& tree, const Ray& r, float t_mi
                 int oi = tree.objects[next[active_mesh_index - 1] - 1];
                 const MeshData& m = S.meshes[S.objects[oi].aux];
                 Hit lh; /* mesh.jl:61-71 */
-                float tm = t_max;
+                real tm = t_max;
                 for (int i = node.left; i <= node.right; ++i) {
                     if (c.st) c.st->prim_tests[REF_MESH]++;
                     Hit h = hit_mesh_triangle(m, i, r, t_min, tm);
@@ -785,10 +902,10 @@ Hit hit_mesh_tree(const ref_scene& S, const Tree& tree, const Ray& r, float t_mi
 }
 
 /* scene_manager.jl:40-53 */
-Hit hit_scene(const ref_scene& S, const Ray& r, float t_min, float t_max, const Ctx& c) {
+Hit hit_scene(const ref_scene& S, const Ray& r, real t_min, real t_max, const Ctx& c) {
     if (c.st) c.st->rays++;
     Hit a;
-    float closest_t = t_max;
+    real closest_t = t_max;
     bool first = true;
     for (const Bucket& b : S.buckets) {
         Hit h = b.is_mesh ? hit_mesh_tree(S, b.tree, r, t_min, closest_t, c) : hit_tree(S, b.tree, r, t_min, closest_t, c, false);
@@ -800,9 +917,9 @@ Hit hit_scene(const ref_scene& S, const Ray& r, float t_min, float t_max, const 
 }
 
 /* ------------------------------------------------------ perlin.jl / texture.jl */
-float perlin_noise(const refPerlin& P, V3 p) { /* perlin.jl:48-85 */
-    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
-    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+real perlin_noise(const refPerlin& P, V3 p) { /* perlin.jl:48-85 */
+    real fx = std::floor(p.x), fy = std::floor(p.y), fz = std::floor(p.z);
+    real u = p.x - fx, v = p.y - fy, w = p.z - fz;
     int i = (int)fx, j = (int)fy, k = (int)fz;
     V3 c[2][2][2];
     for (int dk = 1; dk <= 2; ++dk)
@@ -811,94 +928,94 @@ float perlin_noise(const refPerlin& P, V3 p) { /* perlin.jl:48-85 */
                 int idx = P.perm_x[(i + di) & 255] ^ P.perm_y[(j + dj) & 255] ^ P.perm_z[(k + dk) & 255];
                 c[di - 1][dj - 1][dk - 1] = v3(P.ranvec[3 * idx], P.ranvec[3 * idx + 1], P.ranvec[3 * idx + 2]);
             }
-    float uu = u * u * (3.0f - 2.0f * u);
-    float vv = v * v * (3.0f - 2.0f * v);
-    float ww = w * w * (3.0f - 2.0f * w);
-    float accum = 0.0f;
+    real uu = u * u * (R(3.0) - R(2.0) * u);
+    real vv = v * v * (R(3.0) - R(2.0) * v);
+    real ww = w * w * (R(3.0) - R(2.0) * w);
+    real accum = R(0.0);
     for (int kk = 0; kk <= 1; ++kk)
         for (int jj = 0; jj <= 1; ++jj)
             for (int ii = 0; ii <= 1; ++ii) {
-                V3 weight_v = v3(u - (float)ii, v - (float)jj, w - (float)kk);
-                float fi = (float)ii, fj = (float)jj, fk = (float)kk;
-                accum += (fi * uu + (1.0f - fi) * (1.0f - uu)) * (fj * vv + (1.0f - fj) * (1.0f - vv)) *
-                         (fk * ww + (1.0f - fk) * (1.0f - ww)) * dot(c[ii][jj][kk], weight_v);
+                V3 weight_v = v3(u - (real)ii, v - (real)jj, w - (real)kk);
+                real fi = (real)ii, fj = (real)jj, fk = (real)kk;
+                accum += (fi * uu + (R(1.0) - fi) * (R(1.0) - uu)) * (fj * vv + (R(1.0) - fj) * (R(1.0) - vv)) *
+                         (fk * ww + (R(1.0) - fk) * (R(1.0) - ww)) * dot(c[ii][jj][kk], weight_v);
             }
     return accum;
 }
-float perlin_noise_scalar(const refPerlin& P, V3 p) { /* perlin.jl:48-68,87-97 with Perlin3{Float32}: ranvec[3*i] holds the scalar */
-    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
-    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+real perlin_noise_scalar(const refPerlin& P, V3 p) { /* perlin.jl:48-68,87-97 with Perlin3{Float32}: ranvec[3*i] holds the scalar */
+    real fx = std::floor(p.x), fy = std::floor(p.y), fz = std::floor(p.z);
+    real u = p.x - fx, v = p.y - fy, w = p.z - fz;
     int i = (int)fx, j = (int)fy, k = (int)fz;
-    float accum = 0.0f;
+    real accum = R(0.0);
     for (int kk = 0; kk <= 1; ++kk)
         for (int jj = 0; jj <= 1; ++jj)
             for (int ii = 0; ii <= 1; ++ii) {
                 int idx = P.perm_x[(i + ii + 1) & 255] ^ P.perm_y[(j + jj + 1) & 255] ^ P.perm_z[(k + kk + 1) & 255];
-                float fi = (float)ii, fj = (float)jj, fk = (float)kk;
-                accum += (fi * u + (1.0f - fi) * (1.0f - u)) * (fj * v + (1.0f - fj) * (1.0f - v)) *
-                         (fk * w + (1.0f - fk) * (1.0f - w)) * P.ranvec[3 * idx];
+                real fi = (real)ii, fj = (real)jj, fk = (real)kk;
+                accum += (fi * u + (R(1.0) - fi) * (R(1.0) - u)) * (fj * v + (R(1.0) - fj) * (R(1.0) - v)) *
+                         (fk * w + (R(1.0) - fk) * (R(1.0) - w)) * P.ranvec[3 * idx];
             }
     return accum;
 }
-float turbulence(const refPerlin& P, V3 p) { /* perlin.jl:35-46 depth 7 */
-    float accum = 0.0f, weight = 1.0f;
+real turbulence(const refPerlin& P, V3 p) { /* perlin.jl:35-46 depth 7 */
+    real accum = R(0.0), weight = R(1.0);
     for (int i = 0; i < 7; ++i) {
         accum += weight * perlin_noise(P, p);
-        weight *= 0.5f;
-        p = p * 2.0f;
+        weight *= R(0.5);
+        p = p * R(2.0);
     }
-    return fabsf(accum);
+    return std::fabs(accum);
 }
 
-V3 texture_value(const ref_scene& S, int ti, float u, float v, V3 p) { /* texture.jl:42-100 */
+V3 texture_value(const ref_scene& S, int ti, real u, real v, V3 p) { /* texture.jl:42-100 */
     const refTexture& T = S.textures[ti];
     switch (T.kind) {
         case REF_TEX_SOLID: return v3(T.color[0], T.color[1], T.color[2]);
         case REF_TEX_CHECKER: {
-            float sines = det_sinf(10.0f * p.x) * det_sinf(10.0f * p.y) * det_sinf(10.0f * p.z);
-            return texture_value(S, sines < 0.0f ? T.a : T.b, u, v, p);
+            real sines = det_sin(R(10.0) * p.x) * det_sin(R(10.0) * p.y) * det_sin(R(10.0) * p.z);
+            return texture_value(S, sines < R(0.0) ? T.a : T.b, u, v, p);
         }
         case REF_TEX_IMAGE: {
             const refImage& im = S.images[T.a];
             if (im.width == 0 || im.height == 0) return v3(0, 1, 1);
-            u = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
-            v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-            v = 1.0f - v;
-            int i = (int)(v * (float)im.height); /* trunc */
-            int j = (int)(u * (float)im.width);
+            u = u < R(0.0) ? R(0.0) : (u > R(1.0) ? R(1.0) : u);
+            v = v < R(0.0) ? R(0.0) : (v > R(1.0) ? R(1.0) : v);
+            v = R(1.0) - v;
+            int i = (int)(v * (real)im.height); /* trunc */
+            int j = (int)(u * (real)im.width);
             if (i == 0) i = 1;
             if (j == 0) j = 1;
             const uint8_t* px = &S.image_data[T.a][3 * ((size_t)(i - 1) * im.width + (j - 1))];
-            return v3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+            return v3((real)px[0] / R(255.0), (real)px[1] / R(255.0), (real)px[2] / R(255.0));
         }
         case REF_TEX_NOISE_MARBLE: {
             /* texture.jl:98-100; the reference evaluates the sine in Float64 (scale is Float64); the oracle and
-             * the kernels use the shared float sine, a difference of a few 1e-7 in the returned value */
-            float arg = T.scale * p.z + 10.0f * turbulence(S.perlins[T.a], p);
-            float val = 0.5f * (1.0f + det_sinf(arg));
+             * the kernels use the shared real sine, a difference of a few 1e-7 in the returned value */
+            real arg = T.scale * p.z + R(10.0) * turbulence(S.perlins[T.a], p);
+            real val = R(0.5) * (R(1.0) + det_sin(arg));
             return v3(val);
         }
         case REF_TEX_NOISE_SCALAR: /* texture.jl:79-81 */
-            return v3(1.0f) * perlin_noise_scalar(S.perlins[T.a], T.scale * p);
+            return v3(R(1.0)) * perlin_noise_scalar(S.perlins[T.a], T.scale * p);
     }
     return v3(0);
 }
 
 /* ----------------------------------------------------- material.jl:23-38 */
-inline V3 reflect(V3 v, V3 n) { return v - (2.0f * dot(v, n)) * n; }
-inline V3 refract(V3 direction, V3 normal, float etai_over_etat) {
-    float cos_theta = dot(-direction, normal);
+inline V3 reflect(V3 v, V3 n) { return v - (R(2.0) * dot(v, n)) * n; }
+inline V3 refract(V3 direction, V3 normal, real etai_over_etat) {
+    real cos_theta = dot(-direction, normal);
     V3 perp = etai_over_etat * (direction + cos_theta * normal);
-    V3 parallel = (-sqrtf(fabsf(1.0f - dot(perp, perp)))) * normal;
+    V3 parallel = (-std::sqrt(std::fabs(R(1.0) - dot(perp, perp)))) * normal;
     return perp + parallel;
 }
-inline float schlick(float cos_theta, float eta) {
-    float k = (1.0f - eta) / (1.0f + eta);
-    float r0 = k * k;
-    float x = 1.0f - cos_theta;
-    float x2 = x * x;
-    float x5 = (x2 * x2) * x;
-    return r0 + (1.0f - r0) * x5;
+inline real schlick(real cos_theta, real eta) {
+    real k = (R(1.0) - eta) / (R(1.0) + eta);
+    real r0 = k * k;
+    real x = R(1.0) - cos_theta;
+    real x2 = x * x;
+    real x5 = (x2 * x2) * x;
+    return r0 + (R(1.0) - r0) * x5;
 }
 
 /* hittable.jl:36-75 */
@@ -913,25 +1030,25 @@ void scatter(const ref_scene& S, const Ray& ray, const Hit& h, const Ctx& c, Ray
     } else if (m.type == REF_METAL) {
         V3 reflected = reflect(normalize(ray.d), h.n);
         scattered = Ray{h.p, reflected + m.fuzz * random_in_unit_sphere(c), ray.time};
-        float keep = dot(scattered.d, h.n) > 0.0f ? 1.0f : 0.0f;
+        real keep = dot(scattered.d, h.n) > R(0.0) ? R(1.0) : R(0.0);
         V3 a = texture_value(S, m.texture, h.u, h.v, h.p);
-        attenuation = keep != 0.0f ? a : v3(0); /* Bool * Vec3: false is a strong zero */
+        attenuation = keep != R(0.0) ? a : v3(0); /* Bool * Vec3: false is a strong zero */
     } else if (m.type == REF_DIELECTRIC) {
-        float ratio = h.front ? (1.0f / m.eta) : m.eta;
+        real ratio = h.front ? (R(1.0) / m.eta) : m.eta;
         V3 unit_dir = normalize(ray.d);
-        float cos_theta = fminf(dot(-unit_dir, h.n), 1.0f);
-        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        real cos_theta = std::fmin(dot(-unit_dir, h.n), R(1.0));
+        real sin_theta = std::sqrt(R(1.0) - cos_theta * cos_theta);
         V3 dir;
         /* || short-circuits: the random number is only drawn when total reflection does not apply */
-        if ((ratio * sin_theta > 1.0f) || (schlick(cos_theta, m.eta) > rand_scalar(c))) dir = reflect(unit_dir, h.n);
+        if ((ratio * sin_theta > R(1.0)) || (schlick(cos_theta, m.eta) > rand_scalar(c))) dir = reflect(unit_dir, h.n);
         else dir = refract(unit_dir, h.n, ratio);
         scattered = Ray{h.p, dir, ray.time};
-        attenuation = v3(1.0f);
+        attenuation = v3(R(1.0));
     } else if (m.type == REF_ISOTROPIC) {
         scattered = Ray{h.p, random_in_unit_sphere(c), ray.time};
         attenuation = texture_value(S, m.texture, h.u, h.v, h.p);
     } else {
-        scattered = Ray{v3(0), v3(0), 0.0f};
+        scattered = Ray{v3(0), v3(0), R(0.0)};
         attenuation = v3(0);
     }
 }
@@ -944,12 +1061,12 @@ V3 emit(const ref_scene& S, const Hit& h) {
 
 /* Ray_Tracing.jl:11-29 */
 V3 trace(const ref_scene& S, Ray ray, V3 background, int depth, Ctx& c) {
-    V3 acc = v3(1.0f);
-    V3 color = v3(0.0f);
+    V3 acc = v3(R(1.0));
+    V3 color = v3(R(0.0));
     c.bounce = 0;
     while (depth > 0) {
         if (c.ray_log) c.ray_log->push_back(ray);
-        Hit h = hit_scene(S, ray, 0.001f, INF, c);
+        Hit h = hit_scene(S, ray, R(0.001), INF, c);
         if (h.t == INF) return color + acc * background;
         Ray scattered;
         V3 attenuation;
@@ -965,7 +1082,7 @@ V3 trace(const ref_scene& S, Ray ray, V3 background, int depth, Ctx& c) {
 }
 
 /* camera.jl:38-42 */
-Ray get_ray(const refCamera& cam, float s, float t, Ctx& c) {
+Ray get_ray(const refCamera& cam, real s, real t, Ctx& c) {
     c.bounce = CAMERA_BOUNCE;
     V3 u = v3(cam.u[0], cam.u[1], cam.u[2]), v = v3(cam.v[0], cam.v[1], cam.v[2]);
     V3 origin = v3(cam.origin[0], cam.origin[1], cam.origin[2]);
@@ -974,17 +1091,17 @@ Ray get_ray(const refCamera& cam, float s, float t, Ctx& c) {
     V3 ver = v3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
     V3 rd = cam.lens_radius * random_in_unit_disk(c);
     V3 offset_origin = (u * rd.x + v * rd.y) + origin;
-    float time = rand_scalar(c) * (cam.t1 - cam.t0) + cam.t0;
+    real time = rand_scalar(c) * (cam.t1 - cam.t0) + cam.t0;
     return Ray{offset_origin, ((llc + s * hor) + t * ver) - offset_origin, time};
 }
 
-V3 path_radiance(const ref_scene& S, const refCamera& cam, const float* pattern, int i, int j, int n, int width,
+V3 path_radiance(const ref_scene& S, const refCamera& cam, const real* pattern, int i, int j, int n, int width,
                  int height, V3 background, int max_depth, uint32_t seed32, Stats* st,
                  std::vector<Ray>* ray_log = nullptr) {
     /* Ray_Tracing.jl:83-88 */
-    float dx = pattern[2 * n], dy = pattern[2 * n + 1];
-    float s = ((float)i + dx) / (float)(width - 1);
-    float t = ((float)j + dy) / (float)(height - 1);
+    real dx = pattern[2 * n], dy = pattern[2 * n + 1];
+    real s = ((real)i + dx) / (real)(width - 1);
+    real t = ((real)j + dy) / (real)(height - 1);
     Ctx c;
     c.pixel = (uint32_t)j * (uint32_t)width + (uint32_t)i;
     c.sample = (uint32_t)n;
@@ -1093,8 +1210,8 @@ int ref_scene_create(const refWorld* w, ref_scene** out) {
 
 void ref_scene_destroy(ref_scene* s) { delete s; }
 
-int ref_render(ref_scene* S, const refCamera* cam, const float* pattern, int n, const float background[3], int width,
-               int height, int max_depth, uint64_t seed, int threads, float* out, refStats* stats) {
+int ref_render(ref_scene* S, const refCamera* cam, const real* pattern, int n, const real background[3], int width,
+               int height, int max_depth, uint64_t seed, int threads, real* out, refStats* stats) {
     if (!S || !cam || !pattern || !out || n <= 0 || width <= 1 || height <= 1) { g_err = "bad argument"; return -1; }
     if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
     if (threads <= 0) threads = 1;
@@ -1113,8 +1230,8 @@ int ref_render(ref_scene* S, const refCamera* cam, const float* pattern, int n, 
                 V3 col = v3(0, 0, 0);
                 for (int k = 0; k < n; ++k)
                     col = col + path_radiance(*S, *cam, pattern, i, j, k, width, height, bg, max_depth, seed32, st);
-                col = col * (float)(1.0 / (double)n); /* vec3.jl:31 with an Int divisor */
-                col = v3(sqrtf(col.x), sqrtf(col.y), sqrtf(col.z));
+                col = col * (real)(1.0 / (double)n); /* vec3.jl:31 with an Int divisor */
+                col = v3(std::sqrt(col.x), std::sqrt(col.y), std::sqrt(col.z));
                 size_t idx = ((size_t)i * height + (size_t)(height - 1 - j)) * 3; /* img[height-j, i+1] */
                 out[idx] = col.x; out[idx + 1] = col.y; out[idx + 2] = col.z;
             }
@@ -1139,9 +1256,9 @@ int ref_render(ref_scene* S, const refCamera* cam, const float* pattern, int n, 
     return 0;
 }
 
-int ref_trace_paths(ref_scene* S, const refCamera* cam, const float* pattern, int n, const float background[3],
+int ref_trace_paths(ref_scene* S, const refCamera* cam, const real* pattern, int n, const real background[3],
                     int width, int height, int max_depth, uint64_t seed, const int32_t* ids, int n_paths,
-                    float* radiance) {
+                    real* radiance) {
     if (!S || !cam || !pattern || !ids || !radiance) { g_err = "bad argument"; return -1; }
     V3 bg = v3(background[0], background[1], background[2]);
     uint32_t seed32 = fold_seed(seed);
@@ -1156,8 +1273,8 @@ int ref_trace_paths(ref_scene* S, const refCamera* cam, const float* pattern, in
 
 /* The rays (origin, direction, time) that one path casts, bounce by bounce: for finding the bounce at which
  * another implementation of the same path parts from this one. */
-int ref_path_rays(ref_scene* S, const refCamera* cam, const float* pattern, int n, const float background[3], int width,
-                  int height, int max_depth, uint64_t seed, int i, int j, int s, float* rays, int max_rays) {
+int ref_path_rays(ref_scene* S, const refCamera* cam, const real* pattern, int n, const real background[3], int width,
+                  int height, int max_depth, uint64_t seed, int i, int j, int s, real* rays, int max_rays) {
     if (!S || !cam || !pattern || !rays) { g_err = "bad argument"; return -1; }
     if (i < 0 || i >= width || j < 0 || j >= height || s < 0 || s >= n) { g_err = "path id out of range"; return -1; }
     std::vector<Ray> log;
@@ -1166,18 +1283,18 @@ int ref_path_rays(ref_scene* S, const refCamera* cam, const float* pattern, int 
     int m = (int)log.size() < max_rays ? (int)log.size() : max_rays;
     for (int k = 0; k < m; ++k) {
         const Ray& r = log[k];
-        float* q = &rays[7 * k];
+        real* q = &rays[7 * k];
         q[0] = r.o.x; q[1] = r.o.y; q[2] = r.o.z; q[3] = r.d.x; q[4] = r.d.y; q[5] = r.d.z; q[6] = r.time;
     }
     return m;
 }
 
-int ref_trace_rays(ref_scene* S, const float* rays, int n, float tmin, float tmax, uint64_t seed, int32_t* prim_id,
-                   int32_t* sub_id, float* t, float* normal, float* uv, uint8_t* front) {
+int ref_trace_rays(ref_scene* S, const real* rays, int n, real tmin, real tmax, uint64_t seed, int32_t* prim_id,
+                   int32_t* sub_id, real* t, real* normal, real* uv, uint8_t* front) {
     if (!S || !rays) { g_err = "bad argument"; return -1; }
     uint32_t seed32 = fold_seed(seed);
     for (int k = 0; k < n; ++k) {
-        const float* q = &rays[7 * k];
+        const real* q = &rays[7 * k];
         Ray r{v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5]), q[6]};
         Ctx c;
         c.pixel = (uint32_t)k; c.sample = 0; c.seed32 = seed32; c.bounce = 0;
@@ -1202,7 +1319,7 @@ int ref_bucket_info(ref_scene* S, int b, int32_t* n_objects, int32_t* n_node_slo
     return 0;
 }
 
-int ref_bucket_bvh(ref_scene* S, int b, int32_t* sorted_objects, float* bounds, int32_t* left, int32_t* right,
+int ref_bucket_bvh(ref_scene* S, int b, int32_t* sorted_objects, real* bounds, int32_t* left, int32_t* right,
                    uint8_t* leaf, uint8_t* valid) {
     if (!S || b < 0 || b >= (int)S->buckets.size()) return -1;
     const Tree& t = S->buckets[b].tree;
@@ -1230,7 +1347,7 @@ int ref_mesh_order(ref_scene* S, int mesh, int32_t* tri_order) {
 }
 
 /* MSAA_patterns.jl:25-43 */
-static void halton(int N, int b, float* seq, int stride) {
+static void halton(int N, int b, real* seq, int stride) {
     long long n = 0, d = 1;
     for (int i = 0; i < N; ++i) {
         long long x = d - n;
@@ -1242,25 +1359,29 @@ static void halton(int N, int b, float* seq, int stride) {
             while (x <= y) y /= b;
             n = (b + 1) * y - x;
         }
-        seq[(size_t)i * stride] = (float)n / (float)d; /* T(n) / d with T = Float32 */
+        seq[(size_t)i * stride] = (real)n / (real)d; /* T(n) / d with T = Float32 */
     }
 }
 /* MSAA_patterns.jl:50-58 */
-void ref_halton_sequence32(int n, float* out) {
+void ref_halton_sequence32(int n, real* out) {
     halton(n, 2, out, 2);
     halton(n, 3, out + 1, 2);
-    for (int i = 0; i < 2 * n; ++i) out[i] -= 0.5f;
+    for (int i = 0; i < 2 * n; ++i) out[i] -= R(0.5);
 }
 
 void ref_pcg4d(uint32_t v[4]) { pcg4d(v); }
-float ref_rand01(uint32_t pixel, uint32_t sample, uint32_t counter, uint32_t seed32, int lane) {
+real ref_rand01(uint32_t pixel, uint32_t sample, uint32_t counter, uint32_t seed32, int lane) {
     uint32_t v[4] = {pixel, sample, counter, seed32};
     pcg4d(v);
+#ifdef REF_F64
+    return u64_to_01(v[(2 * lane) & 3], v[(2 * lane + 1) & 3]); /* lane 0 or 1: the two numbers of one hash */
+#else
     return u32_to_01(v[lane & 3]);
+#endif
 }
-float ref_logf(float x) { return det_logf(x); }
-float ref_sinf(float x) { return det_sinf(x); }
-float ref_acosf(float x) { return det_acosf(x); }
-float ref_atan2f(float y, float x) { return det_atan2f(y, x); }
+real ref_logf(real x) { return det_log(x); }
+real ref_sinf(real x) { return det_sin(x); }
+real ref_acosf(real x) { return det_acos(x); }
+real ref_atan2f(real y, real x) { return det_atan2(y, x); }
 
 } // extern "C"

@@ -33,6 +33,15 @@
 extern "C" {
 #endif
 
+/* The element type F of render(F, ...) (main.jl:21,46).  The file is compiled twice: as it stands (Float32, the
+ * reference's default, _build/librt_ref.so) and with -DREF_F64 (Float64, _build/librt_ref64.so: same names, every
+ * ref_real below a double, random numbers of 53 bits). */
+#ifdef REF_F64
+typedef double ref_real;
+#else
+typedef float ref_real;
+#endif
+
 /* object kinds: one per concrete Hittable of the reference */
 enum {
     REF_SPHERE = 1,          /* src/sphere.jl:3   p = cx,cy,cz,r */
@@ -58,20 +67,20 @@ typedef struct refObject {
     int32_t material; /* index into materials, -1 if none */
     int32_t child;    /* index into objects (Transform.object / ConstantMedium.boundary), -1 if none */
     int32_t aux;      /* transform / group / mesh index */
-    float p[12];
+    ref_real p[12];
 } refObject;
 
 typedef struct refTransform {
-    float xform[12]; /* 3x4 column-major, src/transform.jl:65 */
-    float inv[12];
-    float bbox[6];   /* cached world AABB min(3), max(3), src/transform.jl:47-63 */
+    ref_real xform[12]; /* 3x4 column-major, src/transform.jl:65 */
+    ref_real inv[12];
+    ref_real bbox[6];   /* cached world AABB min(3), max(3), src/transform.jl:47-63 */
 } refTransform;
 
 typedef struct refMaterial {
     int32_t type;
     int32_t texture;
-    float fuzz;
-    float eta;
+    ref_real fuzz;
+    ref_real eta;
 } refMaterial;
 
 typedef struct refTexture {
@@ -79,8 +88,8 @@ typedef struct refTexture {
     int32_t a; /* checker: odd texture; image: image index; noise: perlin index */
     int32_t b; /* checker: even texture */
     int32_t pad;
-    float color[3];
-    float scale;
+    ref_real color[3];
+    ref_real scale;
 } refTexture;
 
 typedef struct refImage {
@@ -89,13 +98,13 @@ typedef struct refImage {
 } refImage;
 
 typedef struct refPerlin {
-    float ranvec[256 * 3];
+    ref_real ranvec[256 * 3];
     int32_t perm_x[256], perm_y[256], perm_z[256];
 } refPerlin;
 
 typedef struct refMesh {
     int32_t n_vertices, n_triangles, n_materials, pad;
-    const float* vertices;    /* 8 floats per vertex: position, normal, u, v  (src/vertex.jl:3-8) */
+    const ref_real* vertices;    /* 8 floats per vertex: position, normal, u, v  (src/vertex.jl:3-8) */
     const int32_t* indices;   /* 4 x n_triangles column-major: 3 vertex ids (0-based) + local material id */
     const int32_t* materials; /* local material id -> global material index */
     const int32_t* unused;    /* keeps the layout equal to the product ABI's mesh record */
@@ -119,8 +128,8 @@ typedef struct refWorld {
 } refWorld;
 
 typedef struct refCamera { /* src/camera.jl:3-14 */
-    float origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3], w[3];
-    float lens_radius, t0, t1;
+    ref_real origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    ref_real lens_radius, t0, t1;
 } refCamera;
 
 typedef struct refStats {
@@ -138,46 +147,46 @@ const char* ref_last_error(void);
 
 /* src/Ray_Tracing.jl:71-100: out is 3*H*W floats in the memory order of a Julia
  * Array{RGB{Float32}}(H,W): index ((col*H) + row)*3 + c, row 0 = top. */
-int ref_render(ref_scene*, const refCamera*, const float* pattern /*2 x n col-major*/, int n,
-               const float background[3], int width, int height, int max_depth, uint64_t seed,
-               int threads, float* out, refStats* stats);
+int ref_render(ref_scene*, const refCamera*, const ref_real* pattern /*2 x n col-major*/, int n,
+               const ref_real background[3], int width, int height, int max_depth, uint64_t seed,
+               int threads, ref_real* out, refStats* stats);
 
 /* radiance of single paths: ids = n_paths triples (i = column, j = row from bottom, n = sample, 0-based) */
-int ref_trace_paths(ref_scene*, const refCamera*, const float* pattern, int n,
-                    const float background[3], int width, int height, int max_depth, uint64_t seed,
-                    const int32_t* ids, int n_paths, float* radiance /*3 x n_paths*/);
+int ref_trace_paths(ref_scene*, const refCamera*, const ref_real* pattern, int n,
+                    const ref_real background[3], int width, int height, int max_depth, uint64_t seed,
+                    const int32_t* ids, int n_paths, ref_real* radiance /*3 x n_paths*/);
 
 /* the rays one path casts, bounce by bounce (7 floats each: origin, direction, time); returns how many were
  * written (at most max_rays) or -1.  For finding the bounce at which another implementation parts from this one. */
-int ref_path_rays(ref_scene*, const refCamera*, const float* pattern, int n, const float background[3],
-                  int width, int height, int max_depth, uint64_t seed, int i, int j, int s, float* rays,
+int ref_path_rays(ref_scene*, const refCamera*, const ref_real* pattern, int n, const ref_real background[3],
+                  int width, int height, int max_depth, uint64_t seed, int i, int j, int s, ref_real* rays,
                   int max_rays);
 
 /* closest hit of fixed rays against the whole SceneManager (src/scene_manager.jl:40-53).
  * rays: 7 floats each (origin, direction, time).  prim_id = position in `top`, -1 on miss. */
-int ref_trace_rays(ref_scene*, const float* rays, int n, float tmin, float tmax, uint64_t seed,
-                   int32_t* prim_id, int32_t* sub_id, float* t, float* normal /*3n*/, float* uv /*2n*/,
+int ref_trace_rays(ref_scene*, const ref_real* rays, int n, ref_real tmin, ref_real tmax, uint64_t seed,
+                   int32_t* prim_id, int32_t* sub_id, ref_real* t, ref_real* normal /*3n*/, ref_real* uv /*2n*/,
                    uint8_t* front);
 
 /* bucket / BVH introspection (src/scene_manager.jl:9-19, src/BVH.jl:65-109, src/mesh.jl:217-305) */
 int ref_bucket_count(ref_scene*);
 int ref_bucket_info(ref_scene*, int bucket, int32_t* n_objects, int32_t* n_node_slots, int32_t* is_mesh);
-int ref_bucket_bvh(ref_scene*, int bucket, int32_t* sorted_objects, float* bounds /*6 per slot*/,
+int ref_bucket_bvh(ref_scene*, int bucket, int32_t* sorted_objects, ref_real* bounds /*6 per slot*/,
                    int32_t* left, int32_t* right, uint8_t* leaf, uint8_t* valid);
 /* triangle order of a mesh after the build permuted its index matrix (src/mesh.jl:237):
  * tri_order[k] = original 0-based triangle id now stored in column k */
 int ref_mesh_order(ref_scene*, int mesh, int32_t* tri_order);
 
 /* src/MSAA_patterns.jl:25-58 */
-void ref_halton_sequence32(int n, float* out /*2 x n col-major*/);
+void ref_halton_sequence32(int n, ref_real* out /*2 x n col-major*/);
 
 /* the shared deterministic generator and math kernels */
 void ref_pcg4d(uint32_t v[4]);
-float ref_rand01(uint32_t pixel, uint32_t sample, uint32_t counter, uint32_t seed32, int lane);
-float ref_logf(float x);
-float ref_sinf(float x);
-float ref_acosf(float x);
-float ref_atan2f(float y, float x);
+ref_real ref_rand01(uint32_t pixel, uint32_t sample, uint32_t counter, uint32_t seed32, int lane);
+ref_real ref_logf(ref_real x);
+ref_real ref_sinf(ref_real x);
+ref_real ref_acosf(ref_real x);
+ref_real ref_atan2f(ref_real y, ref_real x);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,85 @@ class rtStats(C.Structure):
                 ("extend_launches", C.c_uint64), ("shade_launches", C.c_uint64)]
 
 
+# ---- F = Float64 (render(Float64, ...), main.jl:21,46): the same records with double fields
+c_f64p = C.POINTER(C.c_double)
+
+
+class rtObject64(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("material", C.c_int32), ("child", C.c_int32), ("aux", C.c_int32),
+                ("p", C.c_double * 12)]
+
+
+class rtTransform64(C.Structure):
+    _fields_ = [("xform", C.c_double * 12), ("inv_xform", C.c_double * 12), ("bbox", C.c_double * 6)]
+
+
+class rtMaterial64(C.Structure):
+    _fields_ = [("type", C.c_int32), ("texture", C.c_int32), ("fuzz", C.c_double), ("eta", C.c_double)]
+
+
+class rtTexture64(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("pad", C.c_int32),
+                ("color", C.c_double * 3), ("scale", C.c_double)]
+
+
+class rtPerlin64(C.Structure):
+    _fields_ = [("ranvec", C.c_double * 768), ("perm_x", C.c_int32 * 256), ("perm_y", C.c_int32 * 256),
+                ("perm_z", C.c_int32 * 256)]
+
+
+class rtMesh64(C.Structure):
+    _fields_ = [("n_vertices", C.c_int32), ("n_triangles", C.c_int32), ("n_materials", C.c_int32),
+                ("pad", C.c_int32), ("vertices", c_f64p), ("indices", c_i32p), ("materials", c_i32p),
+                ("tri_ids", c_i32p)]
+
+
+class rtBvh64(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_objects", C.c_int32), ("objects", c_i32p), ("n_nodes", C.c_int32),
+                ("pad", C.c_int32), ("node_bounds", c_f64p), ("node_left", c_i32p), ("node_right", c_i32p),
+                ("node_leaf", c_u8p)]
+
+
+class rtSceneDesc64(C.Structure):
+    _fields_ = [("n_objects", C.c_int32), ("objects", C.POINTER(rtObject64)),
+                ("n_top", C.c_int32), ("top", c_i32p),
+                ("n_transforms", C.c_int32), ("transforms", C.POINTER(rtTransform64)),
+                ("n_materials", C.c_int32), ("materials", C.POINTER(rtMaterial64)),
+                ("n_textures", C.c_int32), ("textures", C.POINTER(rtTexture64)),
+                ("n_images", C.c_int32), ("images", C.POINTER(rtImage)),
+                ("n_perlins", C.c_int32), ("perlins", C.POINTER(rtPerlin64)),
+                ("n_meshes", C.c_int32), ("meshes", C.POINTER(rtMesh64)),
+                ("n_groups", C.c_int32), ("groups", C.POINTER(rtBvh64)),
+                ("n_buckets", C.c_int32), ("buckets", C.POINTER(rtBvh64))]
+
+
+class rtCamera64(C.Structure):
+    _fields_ = [("origin", C.c_double * 3), ("lower_left_corner", C.c_double * 3), ("horizontal", C.c_double * 3),
+                ("vertical", C.c_double * 3), ("u", C.c_double * 3), ("v", C.c_double * 3), ("w", C.c_double * 3),
+                ("lens_radius", C.c_double), ("t0", C.c_double), ("t1", C.c_double)]
+
+
+class Records:
+    """The record types, pointer type and entry-point suffix of one element type."""
+
+    def __init__(self, np_type, suffix, **types):
+        self.np_type, self.suffix = np_type, suffix
+        self.__dict__.update(types)
+
+    def ptr(self, a):
+        return a.ctypes.data_as(self.real_p)
+
+    def fn(self, name):
+        """the entry point `name` of this element type (rt_render -> rt_render_f64)"""
+        return getattr(lib(), name + self.suffix)
+
+
+def records(np_type):
+    """Records of an element type: numpy.float32 (the reference's default F) or numpy.float64."""
+    import numpy as np
+    return R64 if np.dtype(np_type) == np.float64 else R32
+
+
 # every symbol include/rt_amd.h declares: name -> (restype, argtypes)
 class rtLayout(C.Structure):
     _fields_ = [("nodes_per_layout", C.c_uint32), ("n_prims", C.c_uint32), ("surface_root", C.c_uint32),
@@ -148,6 +227,20 @@ SYMBOLS = {
     "rt_bvh_build": (C.c_int, [C.c_int, c_f32p, c_i32p, c_f32p, c_i32p, c_i32p, c_u8p]),
     "rt_bvh_build_meshes": (C.c_int, [C.c_int, c_i32p, C.POINTER(c_f32p), c_i32p, C.POINTER(c_i32p),
                                       C.POINTER(c_i32p), c_i32p, c_f32p, c_i32p, c_i32p, c_u8p]),
+    "rt_scene_create_f64": (C.c_int, [C.POINTER(rtSceneDesc64), C.c_int, C.POINTER(C.c_void_p)]),
+    "rt_scene_destroy_f64": (C.c_int, [C.c_void_p]),
+    "rt_render_f64": (C.c_int, [C.c_void_p, C.POINTER(rtCamera64), c_f64p, C.c_int, c_f64p, C.c_int, C.c_int, C.c_int,
+                                C.c_uint64, C.c_uint32, c_f64p, C.POINTER(rtStats)]),
+    "rt_render_accumulate_f64": (C.c_int, [C.c_void_p, C.POINTER(rtCamera64), c_f64p, C.c_int, C.c_int, C.c_int, c_f64p,
+                                           C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "rt_finalize_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "rt_trace_rays_f64": (C.c_int, [C.c_void_p, c_f64p, C.c_int, C.c_double, C.c_double, C.c_uint64, c_i32p, c_i32p,
+                                    c_f64p, c_f64p, c_f64p, c_u8p]),
+    "rt_trace_paths_f64": (C.c_int, [C.c_void_p, C.POINTER(rtCamera64), c_f64p, C.c_int, c_f64p, C.c_int, C.c_int, C.c_int,
+                                     C.c_uint64, c_i32p, C.c_int, c_f64p]),
+    "rt_bvh_build_f64": (C.c_int, [C.c_int, c_f64p, c_i32p, c_f64p, c_i32p, c_i32p, c_u8p]),
+    "rt_bvh_build_meshes_f64": (C.c_int, [C.c_int, c_i32p, C.POINTER(c_f64p), c_i32p, C.POINTER(c_i32p),
+                                          C.POINTER(c_i32p), c_i32p, c_f64p, c_i32p, c_i32p, c_u8p]),
 }
 
 _lib = None
@@ -192,3 +285,15 @@ def iptr(a):
 
 def bptr(a):
     return a.ctypes.data_as(c_u8p)
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_f64p)
+
+
+R32 = Records(__import__("numpy").float32, "", real=C.c_float, real_p=c_f32p, rtObject=rtObject, rtTransform=rtTransform,
+              rtMaterial=rtMaterial, rtTexture=rtTexture, rtPerlin=rtPerlin, rtMesh=rtMesh, rtBvh=rtBvh,
+              rtSceneDesc=rtSceneDesc, rtCamera=rtCamera)
+R64 = Records(__import__("numpy").float64, "_f64", real=C.c_double, real_p=c_f64p, rtObject=rtObject64,
+              rtTransform=rtTransform64, rtMaterial=rtMaterial64, rtTexture=rtTexture64, rtPerlin=rtPerlin64,
+              rtMesh=rtMesh64, rtBvh=rtBvh64, rtSceneDesc=rtSceneDesc64, rtCamera=rtCamera64)

@@ -11,180 +11,22 @@
 #include "../../include/rt_amd.h"
 #include "rt_internal.h"
 
-namespace {
+namespace f32 {
+typedef float real;
+#include "bvh_build_impl.h"
+} // namespace f32
+namespace f64 { // render(Float64, ...): boxes and vertices in double, everything else the same
+typedef double real;
+#include "bvh_build_impl.h"
+} // namespace f64
 
-struct Box6 {
-    float v[6];
-};
-
-inline void grow(Box6& b, const float* o) {
-    for (int a = 0; a < 3; ++a) {
-        b.v[a] = std::fmin(b.v[a], o[a]);
-        b.v[3 + a] = std::fmax(b.v[3 + a], o[3 + a]);
-    }
-}
-
-// findmax over (max - min) returns the first maximum (src/BVH.jl:76-77)
-inline int split_axis(const Box6& b) {
-    float ex = b.v[3] - b.v[0], ey = b.v[4] - b.v[1], ez = b.v[5] - b.v[2];
-    int axis = 0;
-    float m = ex;
-    if (ey > m) { m = ey; axis = 1; }
-    if (ez > m) { axis = 2; }
-    return axis;
-}
-
-struct NodeOut {
-    float* bounds;
-    int32_t* left;
-    int32_t* right;
-    uint8_t* leaf;
-    void set(int id, const Box6& b, int l, int r, bool is_leaf) const {
-        std::memcpy(bounds + 6 * (size_t)(id - 1), b.v, sizeof(b.v));
-        left[id - 1] = l;
-        right[id - 1] = r;
-        leaf[id - 1] = is_leaf ? 1 : 0;
-    }
-};
-
-// ---- generic objects: src/BVH.jl:65-96.  order[] is tree.objects, permuted in place.
-struct GenericBuild {
-    const float* bounds;
-    int32_t* order;
-    NodeOut out;
-
-    Box6 enclose(int l, int r) const {
-        Box6 b;
-        std::memcpy(b.v, bounds + 6 * (size_t)order[l - 1], sizeof(b.v));
-        for (int i = l + 1; i <= r; ++i) grow(b, bounds + 6 * (size_t)order[i - 1]);
-        return b;
-    }
-    int build(int id, int l, int r) const {
-        Box6 b = enclose(l, r);
-        if (l == r) {
-            out.set(id, b, l, r, true);
-            return id;
-        }
-        int axis = split_axis(b);
-        const float* bb = bounds;
-        std::stable_sort(order + (l - 1), order + r,
-                         [bb, axis](int32_t x, int32_t y) { return bb[6 * (size_t)x + axis] < bb[6 * (size_t)y + axis]; });
-        int mid = (l + r) / 2;
-        int ln = build(id + 1, l, mid);
-        int rn = build(id + 2 * (mid + 1 - l), mid + 1, r);
-        out.set(id, b, ln, rn, false);
-        return id;
-    }
-};
-
-// ---- meshes: src/mesh.jl:217-283
-struct MeshRef {
-    int nv, nt;
-    const float* vertices; // 8 floats per vertex
-    int32_t* indices;      // 4 per triangle, permuted in place
-    int32_t* tri_ids;
-};
-
-// src/mesh.jl:45-49: minimum/maximum of the positions, padded by the Float64 literal 0.0001, narrowed to Float32
-inline Box6 padded(const float mn[3], const float mx[3]) {
-    Box6 b;
-    for (int a = 0; a < 3; ++a) {
-        b.v[a] = (float)((double)mn[a] - 0.0001);
-        b.v[3 + a] = (float)((double)mx[a] + 0.0001);
-    }
-    return b;
-}
-inline void span_vertex(const MeshRef& m, int vid, float mn[3], float mx[3]) {
-    const float* p = m.vertices + 8 * (size_t)vid;
-    for (int a = 0; a < 3; ++a) {
-        mn[a] = std::fmin(mn[a], p[a]);
-        mx[a] = std::fmax(mx[a], p[a]);
-    }
-}
-Box6 mesh_box_all(const MeshRef& m) {
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int v = 0; v < m.nv; ++v) span_vertex(m, v, mn, mx);
-    return padded(mn, mx);
-}
-Box6 mesh_box_cols(const MeshRef& m, int l, int r) { // columns l..r, 1-based inclusive
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int c = l; c <= r; ++c)
-        for (int k = 0; k < 3; ++k) span_vertex(m, m.indices[4 * (size_t)(c - 1) + k], mn, mx);
-    return padded(mn, mx);
-}
-
-struct MeshBuild {
-    std::vector<MeshRef> meshes;
-    std::vector<Box6> mesh_boxes;
-    int32_t* order; // tree.objects (mesh ids), permuted in place
-    NodeOut out;
-    size_t slots;
-    bool overflow = false;
-
-    void set(int id, const Box6& b, int l, int r, bool leaf) {
-        if (id < 1 || (size_t)id > slots) { overflow = true; return; }
-        out.set(id, b, l, r, leaf);
-    }
-    // src/mesh.jl:217-248
-    int build_tris(MeshRef& m, int id, int l, int r, bool left_child) {
-        const int max_triangles = 1;
-        Box6 b = mesh_box_cols(m, l, r);
-        if (r - l < max_triangles) {
-            set(id, b, l, r, true);
-            return id;
-        }
-        int axis = split_axis(b);
-        struct Col { float key; int32_t idx[4]; int32_t tri; };
-        std::vector<Col> cols((size_t)(r - l + 1));
-        for (int c = l; c <= r; ++c) {
-            Col& col = cols[(size_t)(c - l)];
-            std::memcpy(col.idx, m.indices + 4 * (size_t)(c - 1), sizeof(col.idx));
-            col.tri = m.tri_ids[c - 1];
-            float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-            for (int k = 0; k < 3; ++k) span_vertex(m, col.idx[k], mn, mx);
-            col.key = padded(mn, mx).v[axis];
-        }
-        std::stable_sort(cols.begin(), cols.end(), [](const Col& x, const Col& y) { return x.key < y.key; });
-        for (int c = l; c <= r; ++c) {
-            std::memcpy(m.indices + 4 * (size_t)(c - 1), cols[(size_t)(c - l)].idx, sizeof(cols[0].idx));
-            m.tri_ids[c - 1] = cols[(size_t)(c - l)].tri;
-        }
-        int mid = (l + r) / 2;
-        int ln = build_tris(m, id * 2, l, mid, left_child);
-        int rn = build_tris(m, id * (2 - (left_child ? 1 : 0)) + 1, mid + 1, r, false);
-        set(id, b, ln, rn, false);
-        return id;
-    }
-    // src/mesh.jl:250-283
-    int build_level(int id, int l, int r) {
-        if (l == r) {
-            MeshRef& m = meshes[(size_t)order[r - 1]];
-            int ln = build_tris(m, id * 2, 1, m.nt, true);
-            set(id, mesh_boxes[(size_t)order[l - 1]], ln, r, true);
-            return id;
-        }
-        Box6 b = mesh_boxes[(size_t)order[l - 1]];
-        for (int i = l + 1; i <= r; ++i) grow(b, mesh_boxes[(size_t)order[i - 1]].v);
-        int axis = split_axis(b);
-        const std::vector<Box6>& mb = mesh_boxes;
-        std::stable_sort(order + (l - 1), order + r,
-                         [&mb, axis](int32_t x, int32_t y) { return mb[(size_t)x].v[axis] < mb[(size_t)y].v[axis]; });
-        int mid = (l + r) / 2;
-        int ln = build_level(id * 2, l, mid);
-        int rn = build_level(id * 2 + 1, mid + 1, r);
-        set(id, b, ln, rn, false);
-        return id;
-    }
-};
-
-} // namespace
 
 extern "C" int rt_bvh_build(int n, const float* object_bounds, int32_t* order, float* node_bounds, int32_t* node_left,
                             int32_t* node_right, uint8_t* node_leaf) {
     if (n <= 0 || !object_bounds || !order || !node_bounds || !node_left || !node_right || !node_leaf)
         return rt_fail(RT_EINVAL, "rt_bvh_build: null argument or n <= 0");
     for (int i = 0; i < n; ++i) order[i] = i;
-    GenericBuild g{object_bounds, order, NodeOut{node_bounds, node_left, node_right, node_leaf}};
+    f32::GenericBuild g{object_bounds, order, f32::NodeOut{node_bounds, node_left, node_right, node_leaf}};
     g.build(1, 1, n);
     return RT_OK;
 }
@@ -196,25 +38,66 @@ extern "C" int rt_bvh_build_meshes(int n_meshes, const int32_t* n_vertices, cons
     if (n_meshes <= 0 || !n_vertices || !vertices || !n_triangles || !indices || !tri_ids || !mesh_order ||
         !node_bounds || !node_left || !node_right || !node_leaf)
         return rt_fail(RT_EINVAL, "rt_bvh_build_meshes: null argument or n_meshes <= 0");
-    MeshBuild b;
+    f32::MeshBuild b;
     size_t total = 0;
     for (int m = 0; m < n_meshes; ++m) {
         if (n_triangles[m] <= 0 || n_vertices[m] <= 0) return rt_fail(RT_EINVAL, "rt_bvh_build_meshes: empty mesh");
         for (int k = 0; k < 4 * n_triangles[m]; ++k)
             if ((k & 3) != 3 && (indices[m][k] < 0 || indices[m][k] >= n_vertices[m]))
                 return rt_fail(RT_EINVAL, "rt_bvh_build_meshes: vertex index out of range");
-        MeshRef r{n_vertices[m], n_triangles[m], vertices[m], indices[m], tri_ids[m]};
+        f32::MeshRef r{n_vertices[m], n_triangles[m], vertices[m], indices[m], tri_ids[m]};
         for (int t = 0; t < r.nt; ++t) r.tri_ids[t] = t;
         b.meshes.push_back(r);
-        b.mesh_boxes.push_back(mesh_box_all(r));
+        b.mesh_boxes.push_back(f32::mesh_box_all(r));
         mesh_order[m] = m;
         total += (size_t)n_triangles[m];
     }
     b.slots = 4 * total - 1;
     std::memset(node_leaf, 255, b.slots);
     b.order = mesh_order;
-    b.out = NodeOut{node_bounds, node_left, node_right, node_leaf};
+    b.out = f32::NodeOut{node_bounds, node_left, node_right, node_leaf};
     b.build_level(1, 1, n_meshes);
     if (b.overflow) return rt_fail(RT_EUNSUPPORTED, "rt_bvh_build_meshes: node id exceeds the 4*triangles-1 slots of the reference layout");
+    return RT_OK;
+}
+
+
+extern "C" int rt_bvh_build_f64(int n, const double* object_bounds, int32_t* order, double* node_bounds, int32_t* node_left,
+                            int32_t* node_right, uint8_t* node_leaf) {
+    if (n <= 0 || !object_bounds || !order || !node_bounds || !node_left || !node_right || !node_leaf)
+        return rt_fail(RT_EINVAL, "rt_bvh_build_f64: null argument or n <= 0");
+    for (int i = 0; i < n; ++i) order[i] = i;
+    f64::GenericBuild g{object_bounds, order, f64::NodeOut{node_bounds, node_left, node_right, node_leaf}};
+    g.build(1, 1, n);
+    return RT_OK;
+}
+
+extern "C" int rt_bvh_build_meshes_f64(int n_meshes, const int32_t* n_vertices, const double* const* vertices,
+                                   const int32_t* n_triangles, int32_t* const* indices, int32_t* const* tri_ids,
+                                   int32_t* mesh_order, double* node_bounds, int32_t* node_left, int32_t* node_right,
+                                   uint8_t* node_leaf) {
+    if (n_meshes <= 0 || !n_vertices || !vertices || !n_triangles || !indices || !tri_ids || !mesh_order ||
+        !node_bounds || !node_left || !node_right || !node_leaf)
+        return rt_fail(RT_EINVAL, "rt_bvh_build_meshes_f64: null argument or n_meshes <= 0");
+    f64::MeshBuild b;
+    size_t total = 0;
+    for (int m = 0; m < n_meshes; ++m) {
+        if (n_triangles[m] <= 0 || n_vertices[m] <= 0) return rt_fail(RT_EINVAL, "rt_bvh_build_meshes_f64: empty mesh");
+        for (int k = 0; k < 4 * n_triangles[m]; ++k)
+            if ((k & 3) != 3 && (indices[m][k] < 0 || indices[m][k] >= n_vertices[m]))
+                return rt_fail(RT_EINVAL, "rt_bvh_build_meshes_f64: vertex index out of range");
+        f64::MeshRef r{n_vertices[m], n_triangles[m], vertices[m], indices[m], tri_ids[m]};
+        for (int t = 0; t < r.nt; ++t) r.tri_ids[t] = t;
+        b.meshes.push_back(r);
+        b.mesh_boxes.push_back(f64::mesh_box_all(r));
+        mesh_order[m] = m;
+        total += (size_t)n_triangles[m];
+    }
+    b.slots = 4 * total - 1;
+    std::memset(node_leaf, 255, b.slots);
+    b.order = mesh_order;
+    b.out = f64::NodeOut{node_bounds, node_left, node_right, node_leaf};
+    b.build_level(1, 1, n_meshes);
+    if (b.overflow) return rt_fail(RT_EUNSUPPORTED, "rt_bvh_build_meshes_f64: node id exceeds the 4*triangles-1 slots of the reference layout");
     return RT_OK;
 }

@@ -1,0 +1,1353 @@
+// rt_f64.hip -- the Float64 mode of the path: render(Float64, ...) (main.jl:21,46) on gfx950.
+//
+// The Float32 path (rt_kernels.hip) owes its speed to an arithmetic contract derived for Float32 operation by
+// operation (half-precision culling boxes with proven margins, two node sets, hits held against the reference's leaf
+// boxes).  None of it carries over to another element type, so this mode takes the other road: it walks THE
+// REFERENCE'S OWN TREES (one per type group, src/scene_manager.jl:25-38, as the host built them, src/BVH.jl:65-96,
+// src/mesh.jl:217-283) in the reference's own order (src/BVH.jl:22-53, src/mesh.jl:115-163, right child first) with
+// the reference's own slab test (src/bounding_box.jl:20-67) in double, group after group with the bound handed on as
+// hit(::SceneManager) hands it on (src/scene_manager.jl:40-53).  Every intermediate value is then the reference's by
+// construction, and a picture is the CPU path's bit for bit with no tolerance to derive.
+//
+// Shape on the GPU: one lane = one path (one pattern column at one pixel).  Waves are persistent: a lane whose path has
+// ended takes the next unstarted path (one atomic per wave and refill), so a wave stays full until the frame runs
+// out.  Every bounce walks the trees with a per-lane stack in LDS (node ids, conflict-free: entry e of lane l at
+// e * blockDim + l).  Paths write their radiance to a per-path buffer; rt64_sum_kernel adds them per pixel in
+// pattern-column order, which is the order of the sample loop of draw! (src/Ray_Tracing.jl:82-89).
+// FP64 vector rate on this part is half the packed-FP32 rate and registers hold half as many values; the scene tables
+// stay L2-resident.  No FMA contraction (the file is compiled with -ffp-contract=off like the rest of the library).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "rt_internal.h"
+
+namespace {
+
+typedef double real;
+#define R64_INF (__builtin_inf())
+#define R64_BLOCK 128
+#define R64_STACK 48
+
+#define HIP_TRY64(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return rt_fail(e_ == hipErrorOutOfMemory ? RT_ENOMEM : (e_ == hipErrorNoDevice ? RT_ENODEV : RT_EHIP), \
+                           "%s failed: %s", #expr, hipGetErrorString(e_));                                \
+    } while (0)
+
+// ------------------------------------------------------------------ device tables
+struct Node64 { // src/BVH.jl:5-10
+    real box[6];
+    int32_t left, right; // 1-based node ids / object positions, as the reference stores them
+    int32_t leaf, pad;
+};
+struct Tree64 {
+    int32_t node_base, n_nodes, obj_base, n_objects, is_mesh, pad0, pad1, pad2;
+};
+struct Mesh64 {
+    int32_t vertex_base, index_base, material_base, n_triangles;
+};
+struct Image64 {
+    int32_t width, height;
+    uint32_t offset, pad;
+};
+struct Scene64 {
+    const rtObject64* objects;
+    const int32_t* top_pos;
+    const rtTransform64* transforms;
+    const rtMaterial64* materials;
+    const rtTexture64* textures;
+    const Image64* images;
+    const uint8_t* texels;
+    const rtPerlin64* perlins;
+    const Mesh64* meshes;
+    const real* vertices;      // 8 per vertex
+    const int32_t* indices;    // 4 per triangle
+    const int32_t* tri_ids;
+    const int32_t* mesh_materials;
+    const Node64* nodes;
+    const int32_t* tree_objects;
+    const Tree64* trees;       // the type groups of the SceneManager in order, then the nested trees
+    int32_t n_buckets, n_groups;
+};
+struct Frame64 {
+    rtCamera64 cam;
+    const real* pattern; // 2 x n
+    int32_t n, width, height, max_depth;
+    int32_t first, stride;       // this call's columns: first, first + stride, ...
+    int32_t batch_first, batch_cols; // positions within those columns that this launch traces
+    real bg[3];
+    uint32_t seed32;
+    unsigned long long n_paths;  // batch_cols * width * height
+};
+
+// ------------------------------------------------------------------ src/vec3.jl
+struct V3 {
+    real x, y, z;
+};
+__device__ inline V3 v3(real x, real y, real z) { V3 a; a.x = x; a.y = y; a.z = z; return a; }
+__device__ inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ inline V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ inline V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__device__ inline V3 operator*(V3 a, real b) { return v3(a.x * b, a.y * b, a.z * b); }
+__device__ inline V3 operator*(real a, V3 b) { return v3(a * b.x, a * b.y, a * b.z); }
+__device__ inline V3 div_real(V3 a, real b) { return a * (1.0 / b); } // src/vec3.jl:31: a * F(1/b)
+__device__ inline real dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ inline V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ inline real length(V3 a) { return sqrt(dot(a, a)); }
+__device__ inline V3 normalize(V3 a) { return div_real(a, length(a)); }
+__device__ inline bool almost_zero(V3 a) { return a.x == 0.0 && a.y == 0.0 && a.z == 0.0; } // isapprox(x, 0): x == 0
+
+struct Ray {
+    V3 o, d;
+    real time;
+};
+__device__ inline V3 at(const Ray& r, real t) { return r.o + r.d * t; }
+
+// ------------------------------------------------------------------ deterministic math (IEEE basic operations only)
+__device__ inline real det_log(real x) { // x in (0,1): x = 2^k m, m in [sqrt(1/2), sqrt(2)); atanh series
+    if (x == 0.0) return -R64_INF;
+    const real ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const real Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+    unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    uint32_t hx = (uint32_t)(bits >> 32);
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    int k = (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    bits = ((unsigned long long)hx << 32) | (bits & 0xffffffffull);
+    real m = __longlong_as_double((long long)bits);
+    real f = m - 1.0;
+    real hfsq = 0.5 * f * f;
+    real s = f / (2.0 + f);
+    real z = s * s;
+    real w = z * z;
+    real t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    real t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    real Rr = t2 + t1;
+    real dk = (real)k;
+    return (((s * (hfsq + Rr) + dk * ln2_lo) - hfsq) + f) + dk * ln2_hi;
+}
+__device__ inline real det_sin(real x) { // quadrant by a two-part pi/2, then the sine / cosine kernels
+    const real TWO_OVER_PI = 6.36619772367581382433e-01;
+    const real PIO2_1 = 1.57079632673412561417e+00, PIO2_1T = 6.07710050650619224932e-11;
+    real n = floor(x * TWO_OVER_PI + 0.5);
+    real r = (x - n * PIO2_1) - n * PIO2_1T;
+    long long q = (long long)n;
+    real z = r * r;
+    real sn, cs;
+    {
+        const real S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                   S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+        real p = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+        sn = r + (r * z) * (S1 + z * p);
+    }
+    {
+        const real C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                   C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+        real p = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+        cs = 1.0 - (0.5 * z - z * p);
+    }
+    switch ((int)(q & 3)) {
+        case 0: return sn;
+        case 1: return cs;
+        case 2: return -sn;
+        default: return -cs;
+    }
+}
+__device__ inline real det_atan01(real z) { // z in [0,1]: three half-angle steps, then the odd series
+    z = z / (1.0 + sqrt(1.0 + z * z));
+    z = z / (1.0 + sqrt(1.0 + z * z));
+    z = z / (1.0 + sqrt(1.0 + z * z));
+    real w = z * z;
+    real p = 1.0 / 19.0;
+    p = 1.0 / 17.0 - w * p;
+    p = 1.0 / 15.0 - w * p;
+    p = 1.0 / 13.0 - w * p;
+    p = 1.0 / 11.0 - w * p;
+    p = 1.0 / 9.0 - w * p;
+    p = 1.0 / 7.0 - w * p;
+    p = 1.0 / 5.0 - w * p;
+    p = 1.0 / 3.0 - w * p;
+    p = 1.0 - w * p;
+    return 8.0 * (z * p);
+}
+__device__ inline real det_atan2(real y, real x) {
+    const real PI = 3.14159265358979323846;
+    real ax = fabs(x), ay = fabs(y);
+    real a;
+    if (ax == 0.0 && ay == 0.0) a = 0.0;
+    else if (ax >= ay) a = det_atan01(ay / ax);
+    else a = 0.5 * PI - det_atan01(ax / ay);
+    if (__double_as_longlong(x) < 0) a = PI - a;
+    if (__double_as_longlong(y) < 0) a = -a;
+    return a;
+}
+__device__ inline real det_acos(real c) {
+    real s = sqrt((1.0 - c) * (1.0 + c));
+    return det_atan2(s, c);
+}
+
+// ------------------------------------------------------------------ random numbers: pcg4d(pixel, sample, counter, seed)
+__device__ inline void pcg4d(uint32_t v[4]) {
+    for (int i = 0; i < 4; ++i) v[i] = v[i] * 1664525u + 1013904223u;
+    v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+    for (int i = 0; i < 4; ++i) v[i] ^= v[i] >> 16;
+    v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+}
+// rand(Float64): 53 bits from two words, 27 from the first and 26 from the second
+__device__ inline real u64_to_01(uint32_t hi, uint32_t lo) {
+    return ((real)(hi >> 5) * 67108864.0 + (real)(lo >> 6)) * (1.0 / 9007199254740992.0);
+}
+enum { PURPOSE_TRIAL = 0, PURPOSE_SCALAR = 1, PURPOSE_MEDIUM = 2 };
+enum { CAMERA_BOUNCE = 63 };
+struct Ctx {
+    uint32_t pixel, sample, seed32, bounce;
+    __device__ uint32_t counter(uint32_t purpose, uint32_t k) const { return (bounce << 26) | (purpose << 24) | (k & 0xFFFFFFu); }
+    // numbers 0 and 1 of draw k
+    __device__ void draw2(uint32_t purpose, uint32_t k, real& a, real& b) const {
+        uint32_t v[4] = {pixel, sample, counter(purpose, 2 * k), seed32};
+        pcg4d(v);
+        a = u64_to_01(v[0], v[1]);
+        b = u64_to_01(v[2], v[3]);
+    }
+    // number 2 of draw k
+    __device__ real draw_third(uint32_t purpose, uint32_t k) const {
+        uint32_t v[4] = {pixel, sample, counter(purpose, 2 * k + 1), seed32};
+        pcg4d(v);
+        return u64_to_01(v[0], v[1]);
+    }
+};
+__device__ V3 random_in_unit_sphere(const Ctx& c) { // src/vec3.jl:87-94
+    for (uint32_t k = 0;; ++k) {
+        real a, b;
+        c.draw2(PURPOSE_TRIAL, k, a, b);
+        real d = c.draw_third(PURPOSE_TRIAL, k);
+        V3 p = v3(a * 2.0 + -1.0, b * 2.0 + -1.0, d * 2.0 + -1.0);
+        if (!(dot(p, p) > 1.0)) return p;
+    }
+}
+__device__ V3 random_in_unit_disk(const Ctx& c) { // src/vec3.jl:96-105
+    for (uint32_t k = 0;; ++k) {
+        real a, b;
+        c.draw2(PURPOSE_TRIAL, k, a, b);
+        V3 p = v3(a * 2.0 - 1.0, b * 2.0 - 1.0, 0.0);
+        if (!(dot(p, p) > 1.0)) return p;
+    }
+}
+__device__ real rand_scalar(const Ctx& c) {
+    real a, b;
+    c.draw2(PURPOSE_SCALAR, 0, a, b);
+    return a;
+}
+
+// ------------------------------------------------------------------ src/hit_record.jl
+struct Hit {
+    real t;
+    V3 p, n;
+    real u, v;
+    int32_t material, prim, sub;
+    bool front;
+};
+__device__ inline Hit miss() {
+    Hit h;
+    h.t = R64_INF;
+    h.p = v3(R64_INF, R64_INF, R64_INF);
+    h.n = v3(0.0, 0.0, 0.0);
+    h.u = 0.0; h.v = 0.0;
+    h.material = -1; h.prim = -1; h.sub = 0;
+    h.front = false;
+    return h;
+}
+
+// ------------------------------------------------------------------ src/bounding_box.jl:20-67 (the CPU slab test)
+__device__ inline bool hit_aabb(const real* b, const Ray& r, real t_min, real t_max) {
+    real tmin = (b[0] - r.o.x) / r.d.x;
+    real tmax = (b[3] - r.o.x) / r.d.x;
+    if (tmin > tmax) { real s = tmin; tmin = tmax; tmax = s; }
+    if (tmax < t_max) t_max = tmax;
+    if (tmin > t_min) t_min = tmin;
+    if (t_max <= t_min) return false;
+
+    tmin = (b[1] - r.o.y) / r.d.y;
+    tmax = (b[4] - r.o.y) / r.d.y;
+    if (tmin > tmax) { real s = tmin; tmin = tmax; tmax = s; }
+    if (tmax < t_max) t_max = tmax;
+    if (tmin > t_min) t_min = tmin;
+    if (t_max <= t_min) return false;
+
+    tmin = (b[2] - r.o.z) / r.d.z;
+    tmax = (b[5] - r.o.z) / r.d.z;
+    if (tmin > tmax) { real s = tmin; tmin = tmax; tmax = s; }
+    if (tmax < t_max) t_max = tmax;
+    if (tmin > t_min) t_min = tmin;
+    if (t_max <= t_min) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------ primitives
+__device__ inline void get_sphere_uv(V3 p, real& u, real& v) { // src/sphere.jl:104-108
+    const real PI = 3.14159265358979323846;
+    const real TWO_PI = 2.0 * 3.14159265358979323846;
+    real cy = -p.y;
+    cy = cy < -1.0 ? -1.0 : (cy > 1.0 ? 1.0 : cy);
+    real theta = det_acos(cy);
+    real phi = det_atan2(-p.z, p.x) + PI;
+    u = phi / TWO_PI;
+    v = theta / PI;
+}
+__device__ Hit hit_sphere(V3 center, real radius, int material, const Ray& r, real t_min, real t_max) { // src/sphere.jl:45-102
+    V3 oc = r.o - center;
+    real a = dot(r.d, r.d);
+    real half_b = dot(oc, r.d);
+    real c = dot(oc, oc) - radius * radius;
+    real discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0) return miss();
+    real sqrtd = sqrt(discriminant);
+    real root = (-half_b - sqrtd);
+    if (root < t_min * a || t_max * a < root) {
+        root = (-half_b + sqrtd);
+        if (root < t_min * a || t_max * a < root) return miss();
+    }
+    root /= a;
+    Hit h = miss();
+    h.t = root;
+    h.p = at(r, root);
+    V3 normal = div_real(h.p - center, radius);
+    h.front = dot(r.d, normal) < 0.0;
+    get_sphere_uv(normal, h.u, h.v);
+    h.n = (real)(-1 + ((int)h.front << 1)) * normal;
+    h.material = material;
+    return h;
+}
+// src/aarect.jl:49-119; axis = the constant axis (2: xy_rect, 1: xz_rect, 0: yz_rect)
+__device__ Hit hit_rect(int axis, real a0, real a1, real b0, real b1, real k, int material, const Ray& r, real t_min, real t_max) {
+    real ok, dk, oa, da, ob, db;
+    if (axis == 2) { ok = r.o.z; dk = r.d.z; oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
+    else if (axis == 1) { ok = r.o.y; dk = r.d.y; oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
+    else { ok = r.o.x; dk = r.d.x; oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; }
+    real t = (k - ok) / dk;
+    if (t < t_min || t_max < t) return miss();
+    real a = oa + t * da;
+    real b = ob + t * db;
+    if (a < a0 || a1 < a || b < b0 || b1 < b) return miss();
+    Hit h = miss();
+    h.t = t;
+    if (axis == 2) h.p = v3(a, b, k);
+    else if (axis == 1) h.p = v3(a, k, b);
+    else h.p = v3(k, a, b);
+    V3 normal = axis == 2 ? v3(0, 0, 1) : (axis == 1 ? v3(0, 1, 0) : v3(1, 0, 0));
+    h.front = dot(r.d, normal) < 0.0;
+    h.u = (a - a0) / (a1 - a0);
+    h.v = (b - b0) / (b1 - b0);
+    h.n = (real)(-1 + 2 * (int)h.front) * normal;
+    h.material = material;
+    return h;
+}
+__device__ Hit hit_box(const real* p, int material, const Ray& r, real t_min, real t_max) { // src/box.jl:9-24,43-83
+    Hit closest = miss();
+    for (int s = 0; s < 6; ++s) {
+        Hit h;
+        switch (s) {
+            case 0: h = hit_rect(2, p[0], p[3], p[1], p[4], p[5], material, r, t_min, t_max); break;
+            case 1: h = hit_rect(2, p[0], p[3], p[1], p[4], p[2], material, r, t_min, t_max); break;
+            case 2: h = hit_rect(1, p[0], p[3], p[2], p[5], p[4], material, r, t_min, t_max); break;
+            case 3: h = hit_rect(1, p[0], p[3], p[2], p[5], p[1], material, r, t_min, t_max); break;
+            case 4: h = hit_rect(0, p[1], p[4], p[2], p[5], p[3], material, r, t_min, t_max); break;
+            default: h = hit_rect(0, p[1], p[4], p[2], p[5], p[0], material, r, t_min, t_max); break;
+        }
+        if (h.t < closest.t) {
+            closest = h;
+            closest.sub = s;
+            t_max = h.t;
+        }
+    }
+    return closest;
+}
+// Sphere, MovingSphere, the three rectangles, Box
+__device__ Hit hit_basic(const rtObject64& o, const Ray& r, real t_min, real t_max) {
+    const real* p = o.p;
+    switch (o.kind) {
+        case RT_SPHERE: return hit_sphere(v3(p[0], p[1], p[2]), p[3], o.material, r, t_min, t_max);
+        case RT_MOVING_SPHERE: { // src/sphere.jl:24-26
+            V3 c0 = v3(p[0], p[1], p[2]), c1 = v3(p[4], p[5], p[6]);
+            V3 center = c0 + ((r.time - p[3]) / (p[7] - p[3])) * (c1 - c0);
+            return hit_sphere(center, p[8], o.material, r, t_min, t_max);
+        }
+        case RT_XY_RECT: return hit_rect(2, p[0], p[1], p[2], p[3], p[4], o.material, r, t_min, t_max);
+        case RT_XZ_RECT: return hit_rect(1, p[0], p[1], p[2], p[3], p[4], o.material, r, t_min, t_max);
+        case RT_YZ_RECT: return hit_rect(0, p[0], p[1], p[2], p[3], p[4], o.material, r, t_min, t_max);
+        case RT_BOX: return hit_box(p, o.material, r, t_min, t_max);
+    }
+    return miss();
+}
+// src/transform.jl:76-98
+__device__ inline V3 apply_point(const real* T, V3 v) {
+    return v3(T[0] * v.x + T[3] * v.y + T[6] * v.z + T[9], T[1] * v.x + T[4] * v.y + T[7] * v.z + T[10],
+              T[2] * v.x + T[5] * v.y + T[8] * v.z + T[11]);
+}
+__device__ inline V3 apply_vec(const real* T, V3 v) {
+    return v3(T[0] * v.x + T[3] * v.y + T[6] * v.z, T[1] * v.x + T[4] * v.y + T[7] * v.z, T[2] * v.x + T[5] * v.y + T[8] * v.z);
+}
+// a basic object, or one inside a Transform (src/transform.jl:104-116)
+__device__ Hit hit_simple(const Scene64& S, int oi, const Ray& r, real t_min, real t_max) {
+    const rtObject64& o = S.objects[oi];
+    if (o.kind != RT_TRANSFORM) return hit_basic(o, r, t_min, t_max);
+    const rtTransform64& T = S.transforms[o.aux];
+    Ray rr;
+    rr.o = apply_point(T.inv_xform, r.o);
+    rr.d = apply_vec(T.inv_xform, r.d);
+    rr.time = r.time;
+    Hit h = hit_basic(S.objects[o.child], rr, t_min, t_max);
+    if (h.t == R64_INF) return h;
+    h.p = at(r, h.t);
+    h.n = apply_vec(T.xform, h.n);
+    return h;
+}
+__device__ Hit hit_medium(const Scene64& S, int oi, const Ray& r, real t_min, real t_max, const Ctx& c) { // src/constant_medium.jl:29-65
+    const rtObject64& o = S.objects[oi];
+    real t1 = hit_simple(S, o.child, r, -R64_INF, R64_INF).t;
+    if (t1 == R64_INF) return miss();
+    real t2 = hit_simple(S, o.child, r, t1 + 0.0001, R64_INF).t;
+    if (t2 == R64_INF) return miss();
+    if (t1 < t_min) t1 = t_min;
+    if (t2 > t_max) t2 = t_max;
+    if (t1 >= t2) return miss();
+    if (t1 < 0.0) t1 = 0.0;
+    real ray_length = length(r.d);
+    real distance_inside_boundary = (t2 - t1) * ray_length;
+    real a, b;
+    c.draw2(PURPOSE_MEDIUM, (uint32_t)oi, a, b);
+    real hit_distance = o.p[0] * det_log(a);
+    if (hit_distance > distance_inside_boundary) return miss();
+    Hit h = miss();
+    h.t = t1 + hit_distance / ray_length;
+    h.p = at(r, h.t);
+    h.n = v3(1, 0, 0);
+    h.material = o.material;
+    h.front = false;
+    return h;
+}
+
+// src/triangle.jl:73-91
+__device__ real hit_triangle_geom(V3 v1, V3 v2, V3 v3_, const Ray& r, real t_min, real t_max, V3& normal, real& u, real& v) {
+    V3 e1 = v2 - v1;
+    V3 e2 = v3_ - v1;
+    V3 origin_v1 = v1 - r.o;
+    normal = cross(e1, e2);
+    V3 s = cross(origin_v1, r.d);
+    real c = 1.0 / dot(normal, r.d);
+    u = dot(s, e2) * c;
+    v = dot(s, e1) * -c;
+    real t = dot(normal, origin_v1) * c;
+    if (u < 0.0 || v < 0.0 || u + v > 1.0 || t < t_min || t_max < t) {
+        u = -1.0; v = -1.0;
+        return R64_INF;
+    }
+    return t;
+}
+// src/mesh.jl:53-59 + src/triangle.jl:95-121; col is 1-based
+__device__ Hit hit_mesh_triangle(const Scene64& S, const Mesh64& m, int col, const Ray& r, real t_min, real t_max) {
+    const int32_t* id = S.indices + 4 * ((size_t)m.index_base + (size_t)(col - 1));
+    const real* a = S.vertices + 8 * ((size_t)m.vertex_base + (size_t)id[0]);
+    const real* b = S.vertices + 8 * ((size_t)m.vertex_base + (size_t)id[1]);
+    const real* cc = S.vertices + 8 * ((size_t)m.vertex_base + (size_t)id[2]);
+    V3 normal;
+    real u, v;
+    real t = hit_triangle_geom(v3(a[0], a[1], a[2]), v3(b[0], b[1], b[2]), v3(cc[0], cc[1], cc[2]), r, t_min, t_max, normal, u, v);
+    if (t == R64_INF) return miss();
+    real w = 1.0 - u - v;
+    V3 vn = (v3(a[3], a[4], a[5]) * w + v3(b[3], b[4], b[5]) * u) + v3(cc[3], cc[4], cc[5]) * v;
+    real vu = (a[6] * w + b[6] * u) + cc[6] * v;
+    real vv = (a[7] * w + b[7] * u) + cc[7] * v;
+    // src/triangle.jl:110-115: the flag holds when the interpolated normal is exactly zero, so a mesh that carries
+    // normals is shaded with the geometric one
+    bool normal_flag = almost_zero(vn);
+    bool uv_flag = vu >= 0.0 && vv >= 0.0;
+    if (normal_flag) normal = vn;
+    if (uv_flag) { u = vu; v = vv; }
+    Hit h = miss();
+    h.t = t;
+    h.p = at(r, t);
+    h.front = dot(r.d, normal) < 0.0;
+    h.n = (real)(-1 + ((int)h.front << 1)) * normalize(normal);
+    h.material = S.mesh_materials[m.material_base + id[3]];
+    h.u = u; h.v = v;
+    h.sub = S.tri_ids[(size_t)m.index_base + (size_t)(col - 1)];
+    return h;
+}
+
+// ------------------------------------------------------------------ trees
+// stk: the calling lane's column of the stack in LDS (entry e at stk[e * R64_BLOCK]); sp0: entries already in use
+template <bool NESTED>
+__device__ Hit hit_tree(const Scene64& S, int tree, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp0);
+
+template <bool NESTED>
+__device__ Hit hit_object(const Scene64& S, int oi, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp) {
+    const rtObject64& o = S.objects[oi];
+    if (!NESTED) {
+        if (o.kind == RT_CONSTANT_MEDIUM) return hit_medium(S, oi, r, t_min, t_max, c);
+        if (o.kind == RT_BVH) return hit_tree<true>(S, S.n_buckets + o.aux, r, t_min, t_max, c, stk, sp);
+        if (o.kind == RT_TRANSFORM && S.objects[o.child].kind == RT_BVH) {
+            const rtTransform64& T = S.transforms[o.aux];
+            Ray rr;
+            rr.o = apply_point(T.inv_xform, r.o);
+            rr.d = apply_vec(T.inv_xform, r.d);
+            rr.time = r.time;
+            Hit h = hit_tree<true>(S, S.n_buckets + S.objects[o.child].aux, rr, t_min, t_max, c, stk, sp);
+            if (h.t == R64_INF) return h;
+            h.p = at(r, h.t);
+            h.n = apply_vec(T.xform, h.n);
+            return h;
+        }
+    }
+    return hit_simple(S, oi, r, t_min, t_max);
+}
+
+template <bool NESTED>
+__device__ Hit hit_tree(const Scene64& S, int tree, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp0) { // src/BVH.jl:22-53
+    const Tree64 T = S.trees[tree];
+    Hit closest = miss();
+    if (T.n_nodes == 0) return closest;
+    int n = sp0;
+    stk[(n++) * R64_BLOCK] = 1u;
+    while (n > sp0) {
+        const Node64& node = S.nodes[(size_t)T.node_base + stk[(--n) * R64_BLOCK] - 1u];
+        if (!hit_aabb(node.box, r, t_min, t_max)) continue;
+        if (node.leaf) {
+            // src/hittable.jl:21-31 over objects[left:right]
+            Hit lh = miss();
+            real tm = t_max;
+            for (int i = node.left; i <= node.right; ++i) {
+                int oi = S.tree_objects[T.obj_base + i - 1];
+                Hit h = hit_object<NESTED>(S, oi, r, t_min, tm, c, stk, n);
+                if (h.t < lh.t) {
+                    lh = h;
+                    if (NESTED) lh.sub = oi; else lh.prim = S.top_pos[oi];
+                    tm = lh.t;
+                }
+            }
+            if (lh.t < closest.t) { t_max = lh.t; closest = lh; }
+        } else {
+            stk[(n++) * R64_BLOCK] = (uint32_t)node.left;
+            stk[(n++) * R64_BLOCK] = (uint32_t)node.right;
+        }
+    }
+    return closest;
+}
+
+// src/mesh.jl:115-163: the CPU walk of a tree over meshes (t_max is not narrowed)
+__device__ Hit hit_mesh_tree(const Scene64& S, int tree, const Ray& r, real t_min, real t_max, uint32_t* stk) {
+    const Tree64 T = S.trees[tree];
+    Hit closest = miss();
+    if (T.n_nodes == 0) return closest;
+    int n = 1;
+    stk[0] = 1u;
+    int active_mesh_index = 0;
+    while (n > 0) {
+        if (active_mesh_index == n) {
+            active_mesh_index = 0;
+            n -= 1;
+            continue;
+        }
+        const Node64& node = S.nodes[(size_t)T.node_base + stk[(n - 1) * R64_BLOCK] - 1u];
+        n -= 1;
+        if (!hit_aabb(node.box, r, t_min, t_max)) continue;
+        if (node.leaf) {
+            if (active_mesh_index == 0) {
+                stk[(n++) * R64_BLOCK] = (uint32_t)node.right;
+                active_mesh_index = n;
+                stk[(n++) * R64_BLOCK] = (uint32_t)node.left;
+            } else {
+                int oi = S.tree_objects[T.obj_base + (int)stk[(active_mesh_index - 1) * R64_BLOCK] - 1];
+                const Mesh64 m = S.meshes[S.objects[oi].aux];
+                Hit lh = miss(); // src/mesh.jl:61-71
+                real tm = t_max;
+                for (int i = node.left; i <= node.right; ++i) {
+                    Hit h = hit_mesh_triangle(S, m, i, r, t_min, tm);
+                    if (h.t < lh.t) { lh = h; tm = lh.t; }
+                }
+                if (lh.t < closest.t) { closest = lh; closest.prim = S.top_pos[oi]; }
+            }
+        } else {
+            stk[(n++) * R64_BLOCK] = (uint32_t)node.left;
+            stk[(n++) * R64_BLOCK] = (uint32_t)node.right;
+        }
+    }
+    return closest;
+}
+
+// src/scene_manager.jl:40-53: the closest over the type groups; the bound moves only when a later group's hit replaces
+// the one held
+__device__ Hit hit_scene(const Scene64& S, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk) {
+    Hit a = miss();
+    real closest_t = t_max;
+    for (int b = 0; b < S.n_buckets; ++b) {
+        Hit h = S.trees[b].is_mesh ? hit_mesh_tree(S, b, r, t_min, closest_t, stk) : hit_tree<false>(S, b, r, t_min, closest_t, c, stk, 0);
+        if (b == 0) { a = h; continue; }
+        if (a.t <= h.t) { /* keep a */ }
+        else { closest_t = h.t; a = h; }
+    }
+    return a;
+}
+
+// ------------------------------------------------------------------ src/perlin.jl, src/texture.jl
+__device__ real perlin_noise(const rtPerlin64& P, V3 p) { // src/perlin.jl:48-85
+    real fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
+    real u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    real uu = u * u * (3.0 - 2.0 * u);
+    real vv = v * v * (3.0 - 2.0 * v);
+    real ww = w * w * (3.0 - 2.0 * w);
+    real accum = 0.0;
+    for (int kk = 0; kk <= 1; ++kk)
+        for (int jj = 0; jj <= 1; ++jj)
+            for (int ii = 0; ii <= 1; ++ii) {
+                int idx = P.perm_x[(i + ii + 1) & 255] ^ P.perm_y[(j + jj + 1) & 255] ^ P.perm_z[(k + kk + 1) & 255];
+                V3 cv = v3(P.ranvec[3 * idx], P.ranvec[3 * idx + 1], P.ranvec[3 * idx + 2]);
+                V3 weight_v = v3(u - (real)ii, v - (real)jj, w - (real)kk);
+                real fi = (real)ii, fj = (real)jj, fk = (real)kk;
+                accum += (fi * uu + (1.0 - fi) * (1.0 - uu)) * (fj * vv + (1.0 - fj) * (1.0 - vv)) *
+                         (fk * ww + (1.0 - fk) * (1.0 - ww)) * dot(cv, weight_v);
+            }
+    return accum;
+}
+__device__ real perlin_noise_scalar(const rtPerlin64& P, V3 p) { // src/perlin.jl:48-68,87-97 (Perlin3{F}: ranvec[3 i] is the scalar)
+    real fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
+    real u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    real accum = 0.0;
+    for (int kk = 0; kk <= 1; ++kk)
+        for (int jj = 0; jj <= 1; ++jj)
+            for (int ii = 0; ii <= 1; ++ii) {
+                int idx = P.perm_x[(i + ii + 1) & 255] ^ P.perm_y[(j + jj + 1) & 255] ^ P.perm_z[(k + kk + 1) & 255];
+                real fi = (real)ii, fj = (real)jj, fk = (real)kk;
+                accum += (fi * u + (1.0 - fi) * (1.0 - u)) * (fj * v + (1.0 - fj) * (1.0 - v)) *
+                         (fk * w + (1.0 - fk) * (1.0 - w)) * P.ranvec[3 * idx];
+            }
+    return accum;
+}
+__device__ real turbulence(const rtPerlin64& P, V3 p) { // src/perlin.jl:35-46, depth 7
+    real accum = 0.0, weight = 1.0;
+    for (int i = 0; i < 7; ++i) {
+        accum += weight * perlin_noise(P, p);
+        weight *= 0.5;
+        p = p * 2.0;
+    }
+    return fabs(accum);
+}
+__device__ V3 texture_value(const Scene64& S, int ti, real u, real v, V3 p) { // src/texture.jl:42-100
+    // a checker hands on to one of its two textures, which the host lists before it
+    for (int guard = 0; guard < 16 && S.textures[ti].kind == RT_TEX_CHECKER; ++guard) {
+        real sines = det_sin(10.0 * p.x) * det_sin(10.0 * p.y) * det_sin(10.0 * p.z);
+        ti = sines < 0.0 ? S.textures[ti].a : S.textures[ti].b;
+    }
+    const rtTexture64& T = S.textures[ti];
+    switch (T.kind) {
+        case RT_TEX_SOLID: return v3(T.color[0], T.color[1], T.color[2]);
+        case RT_TEX_IMAGE: {
+            const Image64 im = S.images[T.a];
+            if (im.width == 0 || im.height == 0) return v3(0, 1, 1);
+            u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+            v = 1.0 - v;
+            int i = (int)(v * (real)im.height);
+            int j = (int)(u * (real)im.width);
+            if (i == 0) i = 1;
+            if (j == 0) j = 1;
+            const uint8_t* px = S.texels + im.offset + 3 * ((size_t)(i - 1) * im.width + (j - 1));
+            return v3((real)px[0] / 255.0, (real)px[1] / 255.0, (real)px[2] / 255.0);
+        }
+        case RT_TEX_NOISE_MARBLE: {
+            real arg = T.scale * p.z + 10.0 * turbulence(S.perlins[T.a], p);
+            real val = 0.5 * (1.0 + det_sin(arg));
+            return v3(val, val, val);
+        }
+        case RT_TEX_NOISE_SCALAR: {
+            real val = perlin_noise_scalar(S.perlins[T.a], T.scale * p);
+            return v3(1.0, 1.0, 1.0) * val;
+        }
+    }
+    return v3(0, 0, 0);
+}
+
+// ------------------------------------------------------------------ src/material.jl:23-38, src/hittable.jl:36-83
+__device__ inline V3 reflect(V3 v, V3 n) { return v - (2.0 * dot(v, n)) * n; }
+__device__ inline V3 refract(V3 direction, V3 normal, real etai_over_etat) {
+    real cos_theta = dot(-direction, normal);
+    V3 perp = etai_over_etat * (direction + cos_theta * normal);
+    V3 parallel = (-sqrt(fabs(1.0 - dot(perp, perp)))) * normal;
+    return perp + parallel;
+}
+__device__ inline real schlick(real cos_theta, real eta) {
+    real k = (1.0 - eta) / (1.0 + eta);
+    real r0 = k * k;
+    real x = 1.0 - cos_theta;
+    real x2 = x * x;
+    real x5 = (x2 * x2) * x;
+    return r0 + (1.0 - r0) * x5;
+}
+__device__ void scatter(const Scene64& S, const Ray& ray, const Hit& h, const Ctx& c, Ray& scattered, V3& attenuation) {
+    const rtMaterial64& m = S.materials[h.material];
+    if (m.type == RT_LAMBERTIAN) {
+        V3 dir = h.n + normalize(random_in_unit_sphere(c));
+        if (almost_zero(dir)) dir = h.n;
+        scattered.o = h.p; scattered.d = dir; scattered.time = ray.time;
+        attenuation = texture_value(S, m.texture, h.u, h.v, h.p);
+    } else if (m.type == RT_METAL) {
+        V3 reflected = reflect(normalize(ray.d), h.n);
+        scattered.o = h.p; scattered.d = reflected + m.fuzz * random_in_unit_sphere(c); scattered.time = ray.time;
+        bool keep = dot(scattered.d, h.n) > 0.0;
+        V3 a = texture_value(S, m.texture, h.u, h.v, h.p);
+        attenuation = keep ? a : v3(0, 0, 0); // Bool * Vec3: false is a strong zero
+    } else if (m.type == RT_DIELECTRIC) {
+        real ratio = h.front ? (1.0 / m.eta) : m.eta;
+        V3 unit_dir = normalize(ray.d);
+        real cos_theta = fmin(dot(-unit_dir, h.n), 1.0);
+        real sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+        V3 dir;
+        if ((ratio * sin_theta > 1.0) || (schlick(cos_theta, m.eta) > rand_scalar(c))) dir = reflect(unit_dir, h.n);
+        else dir = refract(unit_dir, h.n, ratio);
+        scattered.o = h.p; scattered.d = dir; scattered.time = ray.time;
+        attenuation = v3(1.0, 1.0, 1.0);
+    } else if (m.type == RT_ISOTROPIC) {
+        scattered.o = h.p; scattered.d = random_in_unit_sphere(c); scattered.time = ray.time;
+        attenuation = texture_value(S, m.texture, h.u, h.v, h.p);
+    } else {
+        scattered.o = v3(0, 0, 0); scattered.d = v3(0, 0, 0); scattered.time = 0.0;
+        attenuation = v3(0, 0, 0);
+    }
+}
+__device__ V3 emit(const Scene64& S, const Hit& h) {
+    const rtMaterial64& m = S.materials[h.material];
+    if (m.type == RT_EMISSIVE) return texture_value(S, m.texture, h.u, h.v, h.p);
+    return v3(0, 0, 0);
+}
+
+// src/camera.jl:38-42
+__device__ Ray get_ray(const rtCamera64& cam, real s, real t, Ctx& c) {
+    c.bounce = CAMERA_BOUNCE;
+    V3 u = v3(cam.u[0], cam.u[1], cam.u[2]), v = v3(cam.v[0], cam.v[1], cam.v[2]);
+    V3 origin = v3(cam.origin[0], cam.origin[1], cam.origin[2]);
+    V3 llc = v3(cam.lower_left_corner[0], cam.lower_left_corner[1], cam.lower_left_corner[2]);
+    V3 hor = v3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
+    V3 ver = v3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
+    V3 rd = cam.lens_radius * random_in_unit_disk(c);
+    V3 offset_origin = (u * rd.x + v * rd.y) + origin;
+    real time = rand_scalar(c) * (cam.t1 - cam.t0) + cam.t0;
+    Ray r;
+    r.o = offset_origin;
+    r.d = ((llc + s * hor) + t * ver) - offset_origin;
+    r.time = time;
+    return r;
+}
+
+// One path's state between bounces (src/Ray_Tracing.jl:11-29 unrolled into a loop a lane can leave and re-enter)
+struct Path {
+    Ray ray;
+    V3 acc, color;
+    int depth;
+    Ctx c;
+};
+__device__ inline void start_path(const Frame64& F, int i, int j, int col, Path& P) { // src/Ray_Tracing.jl:83-88
+    real dx = F.pattern[2 * col], dy = F.pattern[2 * col + 1];
+    real s = ((real)i + dx) / (real)(F.width - 1);
+    real t = ((real)j + dy) / (real)(F.height - 1);
+    P.c.pixel = (uint32_t)j * (uint32_t)F.width + (uint32_t)i;
+    P.c.sample = (uint32_t)col;
+    P.c.seed32 = F.seed32;
+    P.ray = get_ray(F.cam, s, t, P.c);
+    P.acc = v3(1.0, 1.0, 1.0);
+    P.color = v3(0.0, 0.0, 0.0);
+    P.depth = F.max_depth;
+    P.c.bounce = 0;
+}
+// one iteration of the loop of trace(); true when the path has ended (P.color is its radiance)
+__device__ inline bool bounce(const Scene64& S, const Frame64& F, Path& P, uint32_t* stk) {
+    if (P.depth <= 0) return true;
+    Hit h = hit_scene(S, P.ray, 0.001, R64_INF, P.c, stk);
+    if (h.t == R64_INF) {
+        P.color = P.color + P.acc * v3(F.bg[0], F.bg[1], F.bg[2]);
+        return true;
+    }
+    Ray scattered;
+    V3 attenuation;
+    scatter(S, P.ray, h, P.c, scattered, attenuation);
+    P.ray = scattered;
+    P.color = P.color + P.acc * emit(S, h);
+    if (almost_zero(attenuation)) return true;
+    P.acc = P.acc * attenuation;
+    P.depth -= 1;
+    P.c.bounce += 1;
+    return P.depth <= 0;
+}
+
+// ------------------------------------------------------------------ kernels
+// radiance: 3 reals per path of the batch, path = column position in the batch * pixels + pixel (pixel = j * width + i)
+__global__ __launch_bounds__(R64_BLOCK) void rt64_paths_kernel(Scene64 S, Frame64 F, unsigned long long* next_path, real* radiance) {
+    __shared__ uint32_t stack[R64_STACK * R64_BLOCK];
+    uint32_t* stk = stack + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned long long pixels = (unsigned long long)F.width * (unsigned long long)F.height;
+    bool active = false, done = false;
+    unsigned long long mine = 0;
+    Path P;
+    for (;;) {
+        if (!active && !done) {
+            // the lanes of the wave without a path take the next ones together: one atomic
+            unsigned long long want = __ballot(1);
+            unsigned leader = (unsigned)__ffsll((long long)want) - 1u;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(next_path, (unsigned long long)__popcll(want));
+            unsigned lo = __shfl((unsigned)(base & 0xffffffffull), (int)leader);
+            unsigned hi = __shfl((unsigned)(base >> 32), (int)leader);
+            base = ((unsigned long long)hi << 32) | lo;
+            mine = base + (unsigned long long)__popcll(want & ((1ull << lane) - 1ull));
+            if (mine < F.n_paths) {
+                unsigned long long pos = mine / pixels, pixel = mine % pixels;
+                int col = F.first + (F.batch_first + (int)pos) * F.stride;
+                start_path(F, (int)(pixel % (unsigned long long)F.width), (int)(pixel / (unsigned long long)F.width), col, P);
+                active = true;
+            } else {
+                done = true;
+            }
+        }
+        if (!__any(active)) break;
+        if (active) {
+            if (bounce(S, F, P, stk)) {
+                radiance[3 * mine] = P.color.x;
+                radiance[3 * mine + 1] = P.color.y;
+                radiance[3 * mine + 2] = P.color.z;
+                active = false;
+            }
+        }
+    }
+}
+
+// accum (Julia Array{RGB{Float64}}(H, W) order) += the batch's radiances, column after column: the sample loop of draw!
+__global__ void rt64_sum_kernel(const real* radiance, int batch_cols, int width, int height, int first_batch, real* accum) {
+    int pixel = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pixel >= width * height) return;
+    int i = pixel % width, j = pixel / width;
+    size_t out = ((size_t)i * height + (size_t)(height - 1 - j)) * 3;
+    real cx = 0.0, cy = 0.0, cz = 0.0;
+    if (!first_batch) { cx = accum[out]; cy = accum[out + 1]; cz = accum[out + 2]; }
+    size_t pixels = (size_t)width * height;
+    for (int k = 0; k < batch_cols; ++k) {
+        const real* r = radiance + 3 * ((size_t)k * pixels + (size_t)pixel);
+        cx = cx + r[0]; cy = cy + r[1]; cz = cz + r[2];
+    }
+    accum[out] = cx; accum[out + 1] = cy; accum[out + 2] = cz;
+}
+__global__ void rt64_finalize_kernel(const real* accum, real inv_n, size_t count, real* out) { // src/Ray_Tracing.jl:90-91
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < count) out[k] = sqrt(accum[k] * inv_n);
+}
+
+// parity hooks
+__global__ __launch_bounds__(R64_BLOCK) void rt64_trace_rays_kernel(Scene64 S, const real* rays, int n, real t_min, real t_max, uint32_t seed32,
+                                                                  int32_t* prim_id, int32_t* sub_id, real* t, real* normal, real* uv, uint8_t* front) {
+    __shared__ uint32_t stack[R64_STACK * R64_BLOCK];
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const real* q = rays + 7 * (size_t)k;
+    Ray r;
+    r.o = v3(q[0], q[1], q[2]); r.d = v3(q[3], q[4], q[5]); r.time = q[6];
+    Ctx c;
+    c.pixel = (uint32_t)k; c.sample = 0; c.seed32 = seed32; c.bounce = 0;
+    Hit h = hit_scene(S, r, t_min, t_max, c, stack + threadIdx.x);
+    bool hit = !(h.t == R64_INF);
+    if (prim_id) prim_id[k] = hit ? h.prim : -1;
+    if (sub_id) sub_id[k] = hit ? h.sub : -1;
+    if (t) t[k] = h.t;
+    if (normal) { normal[3 * k] = h.n.x; normal[3 * k + 1] = h.n.y; normal[3 * k + 2] = h.n.z; }
+    if (uv) { uv[2 * k] = h.u; uv[2 * k + 1] = h.v; }
+    if (front) front[k] = h.front ? 1 : 0;
+}
+__global__ __launch_bounds__(R64_BLOCK) void rt64_trace_paths_kernel(Scene64 S, Frame64 F, const int32_t* ids, int n_paths, real* radiance) {
+    __shared__ uint32_t stack[R64_STACK * R64_BLOCK];
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_paths) return;
+    Path P;
+    start_path(F, ids[3 * k], ids[3 * k + 1], ids[3 * k + 2], P);
+    while (!bounce(S, F, P, stack + threadIdx.x)) {}
+    radiance[3 * k] = P.color.x; radiance[3 * k + 1] = P.color.y; radiance[3 * k + 2] = P.color.z;
+}
+
+inline uint32_t fold_seed(uint64_t seed) { return (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u); }
+
+} // namespace
+
+// ------------------------------------------------------------------ host side
+struct rtScene64 {
+    int device = 0;
+    Scene64 dev{};
+    std::vector<void*> buffers;
+    real* d_pattern = nullptr; size_t pattern_cap = 0;
+    real* d_radiance = nullptr; size_t radiance_cap = 0; // in reals
+    real* d_accum = nullptr; size_t accum_cap = 0;
+    unsigned long long* d_next = nullptr;
+    int n_cus = 0;
+    int blocks_per_cu = 0; // resident workgroups of rt64_paths_kernel per CU
+};
+
+namespace {
+
+template <typename T>
+int upload64(rtScene64* s, const std::vector<T>& v, const T** out) {
+    void* p = nullptr;
+    size_t bytes = v.size() * sizeof(T);
+    HIP_TRY64(hipMalloc(&p, bytes ? bytes : 16));
+    s->buffers.push_back(p);
+    if (bytes) HIP_TRY64(hipMemcpy(p, v.data(), bytes, hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    return RT_OK;
+}
+
+struct Staged64 {
+    std::vector<rtObject64> objects;
+    std::vector<int32_t> top_pos;
+    std::vector<rtTransform64> transforms;
+    std::vector<rtMaterial64> materials;
+    std::vector<rtTexture64> textures;
+    std::vector<Image64> images;
+    std::vector<uint8_t> texels;
+    std::vector<rtPerlin64> perlins;
+    std::vector<Mesh64> meshes;
+    std::vector<real> vertices;
+    std::vector<int32_t> indices, tri_ids, mesh_materials;
+    std::vector<Node64> nodes;
+    std::vector<int32_t> tree_objects;
+    std::vector<Tree64> trees;
+};
+
+// a plain object (what hit_basic takes)
+bool is_basic(int kind) { return kind >= RT_SPHERE && kind <= RT_BOX; }
+
+// Walks a tree from node 1 the way the kernels do and checks everything they will index; returns the largest number of
+// stack entries a walk can hold (0 on error, message set).
+int check_tree(const rtSceneDesc64& D, const rtBvh64& T, bool nested, int* status) {
+    auto fail = [&](int st, const char* msg) { *status = rt_fail(st, "rt_scene_create_f64: %s", msg); return 0; };
+    if (T.n_nodes <= 0 || T.n_objects <= 0 || !T.objects || !T.node_bounds || !T.node_left || !T.node_right || !T.node_leaf)
+        return fail(RT_EINVAL, "empty or incomplete tree record");
+    for (int i = 0; i < T.n_objects; ++i)
+        if (T.objects[i] < 0 || T.objects[i] >= D.n_objects) return fail(RT_EINVAL, "tree object index out of range");
+    std::vector<uint8_t> seen((size_t)T.n_nodes, 0);
+    struct Item { int id, depth; bool in_mesh; int mesh_pos; };
+    std::vector<Item> todo;
+    todo.push_back(Item{1, 1, false, 0});
+    int deepest = 1;
+    while (!todo.empty()) {
+        Item it = todo.back();
+        todo.pop_back();
+        if (it.id < 1 || it.id > T.n_nodes) return fail(RT_EINVAL, "BVH node id out of range");
+        if (seen[(size_t)it.id - 1]) return fail(RT_EINVAL, "BVH links form a cycle or share a node");
+        seen[(size_t)it.id - 1] = 1;
+        if (it.depth > deepest) deepest = it.depth;
+        uint8_t leaf = T.node_leaf[it.id - 1];
+        if (leaf > 1) return fail(RT_EINVAL, "reached an unused BVH node slot");
+        int l = T.node_left[it.id - 1], r = T.node_right[it.id - 1];
+        if (!leaf) {
+            todo.push_back(Item{l, it.depth + 1, it.in_mesh, it.mesh_pos});
+            todo.push_back(Item{r, it.depth + 1, it.in_mesh, it.mesh_pos});
+            continue;
+        }
+        if (T.kind == 0) {
+            if (l < 1 || r > T.n_objects || l > r) return fail(RT_EINVAL, "BVH leaf range out of bounds");
+            for (int i = l; i <= r; ++i) {
+                const rtObject64& o = D.objects[T.objects[i - 1]];
+                if (o.kind == RT_MESH) return fail(RT_EUNSUPPORTED, "a Mesh is only supported in a type group of meshes");
+                if (nested && !is_basic(o.kind)) return fail(RT_EUNSUPPORTED, "only plain objects are supported inside a nested BVHTree");
+            }
+        } else if (!it.in_mesh) { // a mesh-level leaf: left = the root of the mesh's triangles, right = the mesh's position
+            if (r < 1 || r > T.n_objects) return fail(RT_EINVAL, "mesh position out of range");
+            const rtObject64& o = D.objects[T.objects[r - 1]];
+            if (o.kind != RT_MESH || o.aux < 0 || o.aux >= D.n_meshes) return fail(RT_EINVAL, "mesh tree over a non-mesh object");
+            todo.push_back(Item{l, it.depth + 2, true, r});
+        } else { // a triangle-level leaf: columns left..right of the mesh's index matrix
+            const rtMesh64& M = D.meshes[D.objects[T.objects[it.mesh_pos - 1]].aux];
+            if (l < 1 || r > M.n_triangles || l > r) return fail(RT_EINVAL, "triangle range out of bounds");
+        }
+    }
+    return deepest + 2;
+}
+
+int stage_scene64(const rtSceneDesc64& D, Staged64& H, int* stack_need) {
+    auto fail = [&](int st, const char* msg) { return rt_fail(st, "rt_scene_create_f64: %s", msg); };
+    if (D.n_objects <= 0 || D.n_top <= 0 || D.n_buckets <= 0 || !D.objects || !D.top || !D.buckets) return fail(RT_EINVAL, "scene has no objects");
+    if (D.n_transforms < 0 || D.n_materials < 0 || D.n_textures < 0 || D.n_images < 0 || D.n_perlins < 0 || D.n_meshes < 0 || D.n_groups < 0)
+        return fail(RT_EINVAL, "negative count");
+    if ((D.n_transforms && !D.transforms) || (D.n_materials && !D.materials) || (D.n_textures && !D.textures) || (D.n_images && !D.images) ||
+        (D.n_perlins && !D.perlins) || (D.n_meshes && !D.meshes) || (D.n_groups && !D.groups))
+        return fail(RT_EINVAL, "scene description has a null table with a non-zero count");
+    // textures, materials
+    for (int i = 0; i < D.n_textures; ++i) {
+        const rtTexture64& t = D.textures[i];
+        switch (t.kind) {
+            case RT_TEX_SOLID: break;
+            case RT_TEX_CHECKER:
+                if (t.a < 0 || t.a >= i || t.b < 0 || t.b >= i) return fail(RT_EINVAL, "a checker's textures must be listed before it");
+                break;
+            case RT_TEX_IMAGE: if (t.a < 0 || t.a >= D.n_images) return fail(RT_EINVAL, "image index out of range"); break;
+            case RT_TEX_NOISE_MARBLE: case RT_TEX_NOISE_SCALAR:
+                if (t.a < 0 || t.a >= D.n_perlins) return fail(RT_EINVAL, "perlin index out of range");
+                break;
+            default: return fail(RT_EUNSUPPORTED, "unknown texture kind");
+        }
+    }
+    for (int i = 0; i < D.n_materials; ++i) {
+        const rtMaterial64& m = D.materials[i];
+        if (m.type < RT_LAMBERTIAN || m.type > RT_ISOTROPIC) return fail(RT_EUNSUPPORTED, "unknown material type");
+        if (m.texture < 0 || m.texture >= D.n_textures) return fail(RT_EINVAL, "material texture index out of range");
+    }
+    for (int i = 0; i < D.n_perlins; ++i)
+        for (int k = 0; k < 256; ++k)
+            if ((D.perlins[i].perm_x[k] | D.perlins[i].perm_y[k] | D.perlins[i].perm_z[k]) & ~255)
+                return fail(RT_EINVAL, "perlin permutation entry outside 0..255");
+    for (int i = 0; i < D.n_images; ++i) {
+        const rtImage& im = D.images[i];
+        if (im.width < 0 || im.height < 0 || (im.width > 0 && im.height > 0 && !im.rgb)) return fail(RT_EINVAL, "bad image");
+        Image64 d{im.width, im.height, (uint32_t)H.texels.size(), 0u};
+        size_t bytes = (size_t)3 * (size_t)im.width * (size_t)im.height;
+        if (H.texels.size() + bytes > 0xffffffffull) return fail(RT_EUNSUPPORTED, "more than 4 GiB of texels");
+        if (bytes) H.texels.insert(H.texels.end(), im.rgb, im.rgb + bytes);
+        H.images.push_back(d);
+    }
+    // objects: the nestings the kernels know (those of the Float32 path)
+    for (int i = 0; i < D.n_objects; ++i) {
+        const rtObject64& o = D.objects[i];
+        auto valid = [&](int k) { return k >= 0 && k < D.n_objects; };
+        bool needs_material = true;
+        switch (o.kind) {
+            case RT_SPHERE: case RT_MOVING_SPHERE: case RT_XY_RECT: case RT_XZ_RECT: case RT_YZ_RECT: case RT_BOX: break;
+            case RT_TRANSFORM: {
+                needs_material = false;
+                if (o.aux < 0 || o.aux >= D.n_transforms) return fail(RT_EINVAL, "transform index out of range");
+                if (!valid(o.child)) return fail(RT_EINVAL, "Transform child index out of range");
+                int ck = D.objects[o.child].kind;
+                if (!is_basic(ck) && ck != RT_BVH) return fail(RT_EUNSUPPORTED, "unsupported nesting of Transform / ConstantMedium");
+                break;
+            }
+            case RT_CONSTANT_MEDIUM: {
+                if (!valid(o.child)) return fail(RT_EINVAL, "ConstantMedium boundary index out of range");
+                const rtObject64* b = &D.objects[o.child];
+                if (b->kind == RT_TRANSFORM) {
+                    if (!valid(b->child)) return fail(RT_EINVAL, "Transform child index out of range");
+                    b = &D.objects[b->child];
+                }
+                if (b->kind != RT_SPHERE && b->kind != RT_BOX)
+                    return fail(RT_EUNSUPPORTED, "ConstantMedium boundary must be a Sphere or a Box (optionally inside a Transform)");
+                break;
+            }
+            case RT_BVH:
+                needs_material = false;
+                if (o.aux < 0 || o.aux >= D.n_groups) return fail(RT_EINVAL, "group index out of range");
+                break;
+            case RT_MESH:
+                needs_material = false;
+                if (o.aux < 0 || o.aux >= D.n_meshes) return fail(RT_EINVAL, "mesh index out of range");
+                break;
+            default: return fail(RT_EUNSUPPORTED, "unknown object kind");
+        }
+        if (needs_material && (o.material < 0 || o.material >= D.n_materials)) return fail(RT_EINVAL, "material index out of range");
+    }
+    for (int i = 0; i < D.n_meshes; ++i) {
+        const rtMesh64& M = D.meshes[i];
+        if (M.n_triangles < 0 || M.n_vertices < 0 || M.n_materials < 0) return fail(RT_EINVAL, "mesh with a negative count");
+        if ((M.n_triangles && !M.indices) || (M.n_vertices && !M.vertices) || (M.n_materials && !M.materials))
+            return fail(RT_EINVAL, "mesh has a null table with a non-zero count");
+        for (int t = 0; t < M.n_triangles; ++t) {
+            const int32_t* ix = M.indices + 4 * (size_t)t;
+            for (int k = 0; k < 3; ++k) if (ix[k] < 0 || ix[k] >= M.n_vertices) return fail(RT_EINVAL, "vertex index out of range");
+            if (ix[3] < 0 || ix[3] >= M.n_materials) return fail(RT_EINVAL, "mesh material id out of range");
+        }
+        for (int k = 0; k < M.n_materials; ++k)
+            if (M.materials[k] < 0 || M.materials[k] >= D.n_materials) return fail(RT_EINVAL, "material index out of range");
+        Mesh64 d{(int32_t)(H.vertices.size() / 8), (int32_t)(H.indices.size() / 4), (int32_t)H.mesh_materials.size(), M.n_triangles};
+        H.vertices.insert(H.vertices.end(), M.vertices, M.vertices + (size_t)8 * M.n_vertices);
+        H.indices.insert(H.indices.end(), M.indices, M.indices + (size_t)4 * M.n_triangles);
+        for (int t = 0; t < M.n_triangles; ++t) H.tri_ids.push_back(M.tri_ids ? M.tri_ids[t] : t);
+        H.mesh_materials.insert(H.mesh_materials.end(), M.materials, M.materials + M.n_materials);
+        H.meshes.push_back(d);
+    }
+    // trees: the type groups, then the nested ones
+    int need_main = 0, need_nested = 0;
+    for (int k = 0; k < D.n_buckets + D.n_groups; ++k) {
+        bool nested = k >= D.n_buckets;
+        const rtBvh64& T = nested ? D.groups[k - D.n_buckets] : D.buckets[k];
+        if (nested && T.kind != 0) return fail(RT_EUNSUPPORTED, "nested tree of meshes is not supported");
+        int status = RT_OK;
+        int need = check_tree(D, T, nested, &status);
+        if (!need) return status;
+        if (nested) need_nested = std::max(need_nested, need); else need_main = std::max(need_main, need);
+        Tree64 d{(int32_t)H.nodes.size(), T.n_nodes, (int32_t)H.tree_objects.size(), T.n_objects, T.kind != 0 ? 1 : 0, 0, 0, 0};
+        for (int i = 0; i < T.n_nodes; ++i) {
+            Node64 n;
+            memcpy(n.box, T.node_bounds + 6 * (size_t)i, sizeof(n.box));
+            n.left = T.node_left[i]; n.right = T.node_right[i];
+            n.leaf = T.node_leaf[i] == 1 ? 1 : 0; n.pad = 0;
+            H.nodes.push_back(n);
+        }
+        H.tree_objects.insert(H.tree_objects.end(), T.objects, T.objects + T.n_objects);
+        H.trees.push_back(d);
+    }
+    *stack_need = need_main + need_nested;
+    H.objects.assign(D.objects, D.objects + D.n_objects);
+    H.top_pos.assign((size_t)D.n_objects, -1);
+    for (int i = 0; i < D.n_top; ++i) {
+        if (D.top[i] < 0 || D.top[i] >= D.n_objects) return fail(RT_EINVAL, "top-level object index out of range");
+        H.top_pos[(size_t)D.top[i]] = i;
+    }
+    if (D.n_transforms) H.transforms.assign(D.transforms, D.transforms + D.n_transforms);
+    if (D.n_materials) H.materials.assign(D.materials, D.materials + D.n_materials);
+    if (D.n_textures) H.textures.assign(D.textures, D.textures + D.n_textures);
+    if (D.n_perlins) H.perlins.assign(D.perlins, D.perlins + D.n_perlins);
+    return RT_OK;
+}
+
+template <typename T>
+int grow64(T** buf, size_t* cap, size_t count) {
+    if (*cap >= count && *buf) return RT_OK;
+    if (*buf) { HIP_TRY64(hipFree(*buf)); *buf = nullptr; *cap = 0; }
+    HIP_TRY64(hipMalloc((void**)buf, (count ? count : 1) * sizeof(T)));
+    *cap = count;
+    return RT_OK;
+}
+
+int check_frame64(const char* who, rtScene64* s, const rtCamera64* cam, const real* pattern, int n, const real* bg, int width, int height, int max_depth) {
+    if (!s || !cam || !pattern || !bg) return rt_fail(RT_EINVAL, "%s: null argument", who);
+    if (n <= 0 || width <= 1 || height <= 1 || max_depth < 0) return rt_fail(RT_EINVAL, "%s: bad size (n %d, %d x %d, depth %d)", who, n, width, height, max_depth);
+    if ((unsigned long long)width * (unsigned long long)height > 0x7fffffffull / 3ull) return rt_fail(RT_EINVAL, "%s: image too large", who);
+    return RT_OK;
+}
+
+// the radiance buffer holds this many column batches' worth of paths at most (bytes)
+const size_t R64_RADIANCE_BUDGET = (size_t)8 << 30;
+
+int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n, int first, int stride, const real* bg, int width, int height,
+                 int max_depth, uint64_t seed, real* d_accum, hipStream_t stream) {
+    size_t pixels = (size_t)width * (size_t)height;
+    int count = first < n ? (n - first + stride - 1) / stride : 0;
+    if (count == 0) {
+        HIP_TRY64(hipMemsetAsync(d_accum, 0, 3 * pixels * sizeof(real), stream));
+        return RT_OK;
+    }
+    int st = grow64(&s->d_pattern, &s->pattern_cap, (size_t)2 * (size_t)n);
+    if (st != RT_OK) return st;
+    HIP_TRY64(hipMemcpyAsync(s->d_pattern, pattern, (size_t)2 * n * sizeof(real), hipMemcpyHostToDevice, stream));
+    size_t per_col = 3 * pixels * sizeof(real);
+    int cols_per_batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)count, R64_RADIANCE_BUDGET / per_col));
+    if (const char* e = getenv("RT_AMD_F64_BATCH_COLUMNS")) // for tests: several batches on a small frame
+        if (atoi(e) > 0) cols_per_batch = std::min(cols_per_batch, atoi(e));
+    st = grow64(&s->d_radiance, &s->radiance_cap, (size_t)cols_per_batch * 3 * pixels);
+    if (st != RT_OK) return st;
+    if (!s->d_next) HIP_TRY64(hipMalloc((void**)&s->d_next, sizeof(unsigned long long)));
+    Frame64 F;
+    F.cam = *cam;
+    F.pattern = s->d_pattern;
+    F.n = n; F.width = width; F.height = height; F.max_depth = max_depth;
+    F.first = first; F.stride = stride;
+    F.bg[0] = bg[0]; F.bg[1] = bg[1]; F.bg[2] = bg[2];
+    F.seed32 = fold_seed(seed);
+    for (int b0 = 0; b0 < count; b0 += cols_per_batch) {
+        int cols = std::min(cols_per_batch, count - b0);
+        F.batch_first = b0; F.batch_cols = cols;
+        F.n_paths = (unsigned long long)cols * (unsigned long long)pixels;
+        HIP_TRY64(hipMemsetAsync(s->d_next, 0, sizeof(unsigned long long), stream));
+        // persistent waves: enough workgroups to fill every CU, no more than the paths need
+        unsigned long long wanted = (F.n_paths + R64_BLOCK - 1) / R64_BLOCK;
+        unsigned blocks = (unsigned)std::min<unsigned long long>(wanted, (unsigned long long)s->n_cus * (unsigned long long)s->blocks_per_cu);
+        hipLaunchKernelGGL(rt64_paths_kernel, dim3(blocks), dim3(R64_BLOCK), 0, stream, s->dev, F, s->d_next, s->d_radiance);
+        hipLaunchKernelGGL(rt64_sum_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, (const real*)s->d_radiance, cols, width,
+                           height, b0 == 0 ? 1 : 0, d_accum);
+        HIP_TRY64(hipGetLastError());
+    }
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" int rt_scene_create_f64(const rtSceneDesc64* desc, int device, rtScene64** out) {
+    if (!desc || !out) return rt_fail(RT_EINVAL, "rt_scene_create_f64: null argument");
+    *out = nullptr;
+    // the description is checked before the device is looked for: a bad scene is reported as such on any host
+    Staged64 H;
+    int stack_need = 0;
+    int st = stage_scene64(*desc, H, &stack_need);
+    if (st != RT_OK) return st;
+    if (stack_need > R64_STACK) return rt_fail(RT_EUNSUPPORTED, "rt_scene_create_f64: trees %d levels deep need more than the %d stack entries of a lane", stack_need, R64_STACK);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return rt_fail(RT_ENODEV, "rt_scene_create_f64: no HIP device");
+    if (device < 0 || device >= count) return rt_fail(RT_EINVAL, "rt_scene_create_f64: device %d out of range (0..%d)", device, count - 1);
+    HIP_TRY64(hipSetDevice(device));
+    rtScene64* s = new rtScene64();
+    s->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->n_cus = prop.multiProcessorCount;
+    if (s->n_cus <= 0) s->n_cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->blocks_per_cu, rt64_paths_kernel, R64_BLOCK, 0) != hipSuccess || s->blocks_per_cu <= 0)
+        s->blocks_per_cu = 4;
+    Scene64& d = s->dev;
+#define UP64(field, vec)                                              \
+    do {                                                              \
+        st = upload64(s, vec, &d.field);                              \
+        if (st != RT_OK) { rt_scene_destroy_f64(s); return st; }      \
+    } while (0)
+    UP64(objects, H.objects); UP64(top_pos, H.top_pos); UP64(transforms, H.transforms); UP64(materials, H.materials);
+    UP64(textures, H.textures); UP64(images, H.images); UP64(texels, H.texels); UP64(perlins, H.perlins);
+    UP64(meshes, H.meshes); UP64(vertices, H.vertices); UP64(indices, H.indices); UP64(tri_ids, H.tri_ids);
+    UP64(mesh_materials, H.mesh_materials); UP64(nodes, H.nodes); UP64(tree_objects, H.tree_objects); UP64(trees, H.trees);
+#undef UP64
+    d.n_buckets = desc->n_buckets;
+    d.n_groups = desc->n_groups;
+    *out = s;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_destroy_f64(rtScene64* s) {
+    if (!s) return RT_OK;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : s->buffers) (void)hipFree(p);
+    if (s->d_pattern) (void)hipFree(s->d_pattern);
+    if (s->d_radiance) (void)hipFree(s->d_radiance);
+    if (s->d_accum) (void)hipFree(s->d_accum);
+    if (s->d_next) (void)hipFree(s->d_next);
+    delete s;
+    return RT_OK;
+}
+
+extern "C" int rt_render_accumulate_f64(rtScene64* s, const rtCamera64* camera, const double* pattern, int n, int sample_first, int sample_stride,
+                                        const double background[3], int width, int height, int max_depth, uint64_t seed, double* d_accum, void* stream) {
+    int st = check_frame64("rt_render_accumulate_f64", s, camera, pattern, n, background, width, height, max_depth);
+    if (st != RT_OK) return st;
+    if (!d_accum || sample_first < 0 || sample_stride < 1) return rt_fail(RT_EINVAL, "rt_render_accumulate_f64: bad shard or null accumulator");
+    HIP_TRY64(hipSetDevice(s->device));
+    return accumulate64(s, camera, pattern, n, sample_first, sample_stride, background, width, height, max_depth, seed, d_accum, (hipStream_t)stream);
+}
+
+extern "C" int rt_finalize_f64(rtScene64* s, const double* d_accum, int n_total, int width, int height, double* d_out, void* stream) {
+    if (!s || !d_accum || !d_out || n_total <= 0 || width <= 0 || height <= 0) return rt_fail(RT_EINVAL, "rt_finalize_f64: bad argument");
+    HIP_TRY64(hipSetDevice(s->device));
+    size_t count = (size_t)3 * (size_t)width * (size_t)height;
+    real inv_n = (real)(1.0 / (double)n_total); // src/vec3.jl:31 with an Int divisor
+    hipLaunchKernelGGL(rt64_finalize_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_accum, inv_n, count, d_out);
+    HIP_TRY64(hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_render_f64(rtScene64* s, const rtCamera64* camera, const double* pattern, int n, const double background[3], int width, int height,
+                             int max_depth, uint64_t seed, uint32_t flags, double* out, rtStats* stats) {
+    (void)flags;
+    int st = check_frame64("rt_render_f64", s, camera, pattern, n, background, width, height, max_depth);
+    if (st != RT_OK) return st;
+    if (!out) return rt_fail(RT_EINVAL, "rt_render_f64: null output");
+    HIP_TRY64(hipSetDevice(s->device));
+    size_t count = (size_t)3 * (size_t)width * (size_t)height;
+    st = grow64(&s->d_accum, &s->accum_cap, count);
+    if (st != RT_OK) return st;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY64(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return rt_fail(RT_EHIP, "rt_render_f64: hipEventCreate failed"); }
+    (void)hipEventRecord(e0, nullptr);
+    st = accumulate64(s, camera, pattern, n, 0, 1, background, width, height, max_depth, seed, s->d_accum, nullptr);
+    if (st == RT_OK) st = rt_finalize_f64(s, s->d_accum, n, width, height, s->d_accum, nullptr);
+    (void)hipEventRecord(e1, nullptr);
+    hipError_t e = st == RT_OK ? hipMemcpy(out, s->d_accum, count * sizeof(real), hipMemcpyDeviceToHost) : hipSuccess;
+    float ms = 0.0f;
+    if (st == RT_OK && e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (st != RT_OK) return st;
+    if (e != hipSuccess) return rt_fail(RT_EHIP, "rt_render_f64: %s", hipGetErrorString(e));
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->seconds = ms * 1e-3;
+        stats->paths = (uint64_t)width * (uint64_t)height * (uint64_t)n;
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_trace_rays_f64(rtScene64* s, const double* rays, int n, double t_min, double t_max, uint64_t seed, int32_t* prim_id, int32_t* sub_id,
+                                 double* t, double* normal, double* uv, uint8_t* front) {
+    if (!s || !rays || n < 0) return rt_fail(RT_EINVAL, "rt_trace_rays_f64: bad argument");
+    if (n == 0) return RT_OK;
+    HIP_TRY64(hipSetDevice(s->device));
+    real *d_rays = nullptr, *d_t = nullptr, *d_n = nullptr, *d_uv = nullptr;
+    int32_t *d_prim = nullptr, *d_sub = nullptr;
+    uint8_t* d_front = nullptr;
+    int st = RT_OK;
+    auto body = [&]() -> int {
+        HIP_TRY64(hipMalloc((void**)&d_rays, (size_t)7 * n * sizeof(real)));
+        HIP_TRY64(hipMalloc((void**)&d_t, (size_t)n * sizeof(real)));
+        HIP_TRY64(hipMalloc((void**)&d_n, (size_t)3 * n * sizeof(real)));
+        HIP_TRY64(hipMalloc((void**)&d_uv, (size_t)2 * n * sizeof(real)));
+        HIP_TRY64(hipMalloc((void**)&d_prim, (size_t)n * sizeof(int32_t)));
+        HIP_TRY64(hipMalloc((void**)&d_sub, (size_t)n * sizeof(int32_t)));
+        HIP_TRY64(hipMalloc((void**)&d_front, (size_t)n));
+        HIP_TRY64(hipMemcpy(d_rays, rays, (size_t)7 * n * sizeof(real), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(rt64_trace_rays_kernel, dim3((unsigned)((n + R64_BLOCK - 1) / R64_BLOCK)), dim3(R64_BLOCK), 0, nullptr, s->dev,
+                           (const real*)d_rays, n, t_min, t_max, fold_seed(seed), d_prim, d_sub, d_t, d_n, d_uv, d_front);
+        HIP_TRY64(hipGetLastError());
+        HIP_TRY64(hipDeviceSynchronize());
+        if (prim_id) HIP_TRY64(hipMemcpy(prim_id, d_prim, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (sub_id) HIP_TRY64(hipMemcpy(sub_id, d_sub, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (t) HIP_TRY64(hipMemcpy(t, d_t, (size_t)n * sizeof(real), hipMemcpyDeviceToHost));
+        if (normal) HIP_TRY64(hipMemcpy(normal, d_n, (size_t)3 * n * sizeof(real), hipMemcpyDeviceToHost));
+        if (uv) HIP_TRY64(hipMemcpy(uv, d_uv, (size_t)2 * n * sizeof(real), hipMemcpyDeviceToHost));
+        if (front) HIP_TRY64(hipMemcpy(front, d_front, (size_t)n, hipMemcpyDeviceToHost));
+        return RT_OK;
+    };
+    st = body();
+    (void)hipFree(d_rays); (void)hipFree(d_t); (void)hipFree(d_n); (void)hipFree(d_uv); (void)hipFree(d_prim); (void)hipFree(d_sub); (void)hipFree(d_front);
+    return st;
+}
+
+extern "C" int rt_trace_paths_f64(rtScene64* s, const rtCamera64* camera, const double* pattern, int n, const double background[3], int width,
+                                  int height, int max_depth, uint64_t seed, const int32_t* ids, int n_paths, double* radiance) {
+    int st = check_frame64("rt_trace_paths_f64", s, camera, pattern, n, background, width, height, max_depth);
+    if (st != RT_OK) return st;
+    if (!ids || !radiance || n_paths < 0) return rt_fail(RT_EINVAL, "rt_trace_paths_f64: bad argument");
+    if (n_paths == 0) return RT_OK;
+    for (int k = 0; k < n_paths; ++k) {
+        int i = ids[3 * k], j = ids[3 * k + 1], c = ids[3 * k + 2];
+        if (i < 0 || i >= width || j < 0 || j >= height || c < 0 || c >= n) return rt_fail(RT_EINVAL, "rt_trace_paths_f64: path id out of range");
+    }
+    HIP_TRY64(hipSetDevice(s->device));
+    st = grow64(&s->d_pattern, &s->pattern_cap, (size_t)2 * (size_t)n);
+    if (st != RT_OK) return st;
+    HIP_TRY64(hipMemcpy(s->d_pattern, pattern, (size_t)2 * n * sizeof(real), hipMemcpyHostToDevice));
+    int32_t* d_ids = nullptr;
+    real* d_rad = nullptr;
+    auto body = [&]() -> int {
+        HIP_TRY64(hipMalloc((void**)&d_ids, (size_t)3 * n_paths * sizeof(int32_t)));
+        HIP_TRY64(hipMalloc((void**)&d_rad, (size_t)3 * n_paths * sizeof(real)));
+        HIP_TRY64(hipMemcpy(d_ids, ids, (size_t)3 * n_paths * sizeof(int32_t), hipMemcpyHostToDevice));
+        Frame64 F;
+        F.cam = *camera;
+        F.pattern = s->d_pattern;
+        F.n = n; F.width = width; F.height = height; F.max_depth = max_depth;
+        F.first = 0; F.stride = 1; F.batch_first = 0; F.batch_cols = n;
+        F.bg[0] = background[0]; F.bg[1] = background[1]; F.bg[2] = background[2];
+        F.seed32 = fold_seed(seed);
+        F.n_paths = (unsigned long long)n_paths;
+        hipLaunchKernelGGL(rt64_trace_paths_kernel, dim3((unsigned)((n_paths + R64_BLOCK - 1) / R64_BLOCK)), dim3(R64_BLOCK), 0, nullptr, s->dev, F,
+                           (const int32_t*)d_ids, n_paths, d_rad);
+        HIP_TRY64(hipGetLastError());
+        HIP_TRY64(hipDeviceSynchronize());
+        HIP_TRY64(hipMemcpy(radiance, d_rad, (size_t)3 * n_paths * sizeof(real), hipMemcpyDeviceToHost));
+        return RT_OK;
+    };
+    st = body();
+    (void)hipFree(d_ids); (void)hipFree(d_rad);
+    return st;
+}

@@ -1,13 +1,31 @@
 """Host-side mirror of the reference's scene vocabulary (Vec3, Material, textures, the
 Hittable types, Camera, sub-pixel patterns).  Names, argument order and arithmetic
 follow the Julia sources so that scene scripts and tests read like the reference's.
-All geometry is Float32 (the reference's default F).
+The element type F of render(F, ...) (main.jl:21) is the module variable `F`: numpy.float32, the reference's
+default, unless code runs inside `with element_type(numpy.float64):` -- every constructor and helper below reads it
+when it is called, as the reference's take Vec3{F}.
 """
+import contextlib
 import math
 
 import numpy as np
 
 F = np.float32
+
+
+@contextlib.contextmanager
+def element_type(T):
+    """Scenes, cameras and patterns made inside the block have element type T (numpy.float32 or numpy.float64):
+    the F of render(F, ...), get_scene(key; F=F) and Vec3{F} (main.jl:21,90-94)."""
+    global F
+    T = np.dtype(T).type
+    if T not in (np.float32, np.float64):
+        raise TypeError("element type must be float32 or float64")
+    old, F = F, T
+    try:
+        yield
+    finally:
+        F = old
 
 # material types, src/material.jl:3-9
 Lambertian, Metal, Dielectric, Emissive, Isotropic = 1, 2, 3, 4, 5

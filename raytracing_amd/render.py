@@ -16,17 +16,17 @@ F = np.float32
 DEFAULT_SEED = 0x5EED
 
 
-def camera_record(cam):
-    c = ffi.rtCamera()
+def camera_record(cam, rec=ffi.R32):
+    c = rec.rtCamera()
     for name in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w"):
         getattr(c, name)[:] = [float(x) for x in getattr(cam, name)]
     c.lens_radius, c.t0, c.t1 = float(cam.lens_radius), float(cam.t0), float(cam.t1)
     return c
 
 
-def _pattern(pattern):
+def _pattern(pattern, dtype=F):
     """pattern is [x_0 ... x_n; y_0 ... y_n] (2 x N); the ABI wants it column-major like Julia stores it."""
-    p = np.asarray(pattern, dtype=F)
+    p = np.asarray(pattern, dtype=dtype)
     assert p.ndim == 2 and p.shape[0] == 2, "pattern must be 2 x N"
     return np.ascontiguousarray(p.T).reshape(-1), p.shape[1]
 
@@ -82,18 +82,28 @@ class DeviceScene:
     """What draw!(::CuArray, ...) builds before its kernel launch (src/Ray_Tracing.jl:144-145):
     bvh = build_bvh(world); cu_bvh = CuSceneManager(bvh) -- here a scene resident in one GPU's HBM."""
 
-    def __init__(self, world, device=0):
+    def __init__(self, world, device=0, F=np.float32):
+        """F: the element type of render(F, ...) (main.jl:21): numpy.float32, or numpy.float64 for the Float64 entry
+        points (rt_*_f64: render, accumulate, finalize and the two parity hooks; the other methods are Float32 only)."""
+        self.rec = ffi.records(F)
+        self.F = self.rec.np_type
         self.world = list(world)
-        self.scene_manager = SceneManager(self.world)
-        self.bvh = build_bvh_scene(self.scene_manager)
-        desc, keep = flatten_scene(self.world, self.bvh)
+        with H.element_type(self.F):
+            self.scene_manager = SceneManager(self.world)
+            self.bvh = build_bvh_scene(self.scene_manager)
+            desc, keep = flatten_scene(self.world, self.bvh)
         self._keep = keep
         self.handle = C.c_void_p()
-        ffi.check(ffi.lib().rt_scene_create(C.byref(desc), int(device), C.byref(self.handle)))
+        ffi.check(self.rec.fn("rt_scene_create")(C.byref(desc), int(device), C.byref(self.handle)))
+
+    def _f32_only(self, what):
+        if self.rec is not ffi.R32:
+            raise ffi.RtError(f"{what} exists for Float32 scenes only")
 
     def layout(self):
         """The node sets as they are on the device (rt_scene_nodes): (info, nodes, prim_top, build) with info, nodes and
         prim_top as scene_layout() returns them and build = rtBuildInfo (who built the trees, and how)."""
+        self._f32_only("layout()")
         info, build = ffi.rtLayout(), ffi.rtBuildInfo()
         L = ffi.lib()
         ffi.check(L.rt_scene_nodes(self.handle, C.byref(info), None, 0, None, 0, None))
@@ -105,6 +115,7 @@ class DeviceScene:
 
     def pairs(self):
         """The pair nodes as they are on the device (rt_scene_pairs): (pairs, in_use), pairs as scene_layout_pairs()"""
+        self._f32_only("pairs()")
         info = self.layout()[0]
         L = ffi.lib()
         n, used = C.c_uint32(0), C.c_uint32(0)
@@ -119,6 +130,7 @@ class DeviceScene:
         """A scene written by save_scene (rt_scene_desc_load + rt_scene_create): no world list, no tree build."""
         self = cls.__new__(cls)
         self.world = self.scene_manager = self.bvh = self._keep = None
+        self.rec, self.F = ffi.R32, np.float32
         self.handle = C.c_void_p()
         desc = C.POINTER(ffi.rtSceneDesc)()
         L = ffi.lib()
@@ -131,7 +143,7 @@ class DeviceScene:
 
     def close(self):
         if self.handle:
-            ffi.lib().rt_scene_destroy(self.handle)
+            self.rec.fn("rt_scene_destroy")(self.handle)
             self.handle = C.c_void_p()
 
     def __del__(self):
@@ -141,31 +153,35 @@ class DeviceScene:
             pass
 
     def render(self, camera, pattern, background, width, height, max_depth=50, seed=DEFAULT_SEED, flags=0):
-        """Returns (img, stats): img is (height, width, 3) float32, row 0 = top, sqrt-gamma, unclamped."""
-        pat, n = _pattern(pattern)
+        """Returns (img, stats): img is (height, width, 3) of the scene's element type, row 0 = top, sqrt-gamma,
+        unclamped."""
+        rec, F = self.rec, self.F
+        pat, n = _pattern(pattern, F)
         bg = np.asarray(background, dtype=F)
         out = np.zeros(3 * width * height, dtype=F)
         st = ffi.rtStats()
-        cam = camera_record(camera)
-        ffi.check(ffi.lib().rt_render(self.handle, C.byref(cam), ffi.fptr(pat), n, ffi.fptr(bg), width, height,
-                                      max_depth, seed, flags, ffi.fptr(out), C.byref(st)))
+        cam = camera_record(camera, rec)
+        ffi.check(rec.fn("rt_render")(self.handle, C.byref(cam), rec.ptr(pat), n, rec.ptr(bg), width, height,
+                                      max_depth, seed, flags, rec.ptr(out), C.byref(st)))
         # Julia Array{RGB}(H, W) memory order is [col][row][rgb]
         return out.reshape(width, height, 3).transpose(1, 0, 2).copy(), st
 
     def accumulate(self, camera, pattern, background, width, height, d_accum, sample_first=0, sample_stride=1,
                    max_depth=50, seed=DEFAULT_SEED, flags=0, stream=None):
         """Un-normalised sums of this shard's samples into device memory (d_accum = device pointer)."""
-        pat, n = _pattern(pattern)
+        rec, F = self.rec, self.F
+        pat, n = _pattern(pattern, F)
         bg = np.asarray(background, dtype=F)
-        cam = camera_record(camera)
-        ffi.check(ffi.lib().rt_render_accumulate(self.handle, C.byref(cam), ffi.fptr(pat), n, sample_first,
-                                                 sample_stride, ffi.fptr(bg), width, height, max_depth, seed, flags,
-                                                 C.c_void_p(d_accum), C.c_void_p(stream or 0)))
+        cam = camera_record(camera, rec)
+        args = [self.handle, C.byref(cam), rec.ptr(pat), n, sample_first, sample_stride, rec.ptr(bg), width, height,
+                max_depth, seed] + ([flags] if rec is ffi.R32 else []) + [C.c_void_p(d_accum), C.c_void_p(stream or 0)]
+        ffi.check(rec.fn("rt_render_accumulate")(*args))
 
     def accumulate_static(self, camera, pattern, background, width, height, d_accum, sample_first=0, sample_stride=1,
                           max_depth=50, seed=DEFAULT_SEED, stream=None):
         """accumulate() without any device allocation (rt_render_accumulate_static): the working buffers are a fixed
         array inside the library; at most RT_STATIC_MAX_COLUMNS pattern columns and RT_STATIC_MAX_PIXELS pixels."""
+        self._f32_only("accumulate_static()")
         pat, n = _pattern(pattern)
         bg = np.asarray(background, dtype=F)
         cam = camera_record(camera)
@@ -174,11 +190,12 @@ class DeviceScene:
                                                         C.c_void_p(d_accum), C.c_void_p(stream or 0)))
 
     def finalize(self, d_accum, n_total, width, height, d_out, stream=None):
-        ffi.check(ffi.lib().rt_finalize(self.handle, C.c_void_p(d_accum), n_total, width, height,
+        ffi.check(self.rec.fn("rt_finalize")(self.handle, C.c_void_p(d_accum), n_total, width, height,
                                         C.c_void_p(d_out), C.c_void_p(stream or 0)))
 
     def finalize_rgb8(self, d_accum, n_total, width, height, d_rgb8, stream=None):
         """rt_finalize + clamp01 + 8-bit quantisation on the device; d_rgb8 receives height x width x 3 bytes."""
+        self._f32_only("finalize_rgb8()")
         ffi.check(ffi.lib().rt_finalize_rgb8(self.handle, C.c_void_p(d_accum), n_total, width, height,
                                              C.c_void_p(d_rgb8), C.c_void_p(stream or 0)))
 
@@ -190,6 +207,7 @@ class DeviceScene:
         render()), state a dict of host arrays {"accum", "next", "passes", "n", "done"} that np.savez can store and a
         later call takes back through `state=` to go on where it stopped.  After the last shard the image equals
         render()'s up to the order of the float32 sums."""
+        self._f32_only("render_progressive()")
         import torch
         if not torch.cuda.is_available():
             raise ffi.RtError("render_progressive keeps its accumulators in torch tensors and torch sees no GPU; if the "
@@ -219,28 +237,31 @@ class DeviceScene:
             yield dict(accum=total.cpu().numpy(), next=c + 1, passes=passes, n=n, done=done), img
 
     def counters(self):
+        self._f32_only("counters()")
         st = ffi.rtStats()
         ffi.check(ffi.lib().rt_get_counters(self.handle, C.byref(st)))
         return st
 
     def trace_rays(self, rays, t_min=0.001, t_max=np.inf, seed=DEFAULT_SEED):
+        rec, F = self.rec, self.F
         rays = np.ascontiguousarray(rays, dtype=F).reshape(-1, 7)
         n = rays.shape[0]
         out = dict(prim_id=np.zeros(n, np.int32), sub_id=np.zeros(n, np.int32), t=np.zeros(n, F),
                    normal=np.zeros((n, 3), F), uv=np.zeros((n, 2), F), front=np.zeros(n, np.uint8))
-        ffi.check(ffi.lib().rt_trace_rays(self.handle, ffi.fptr(rays), n, float(t_min), float(t_max), seed,
-                                          ffi.iptr(out["prim_id"]), ffi.iptr(out["sub_id"]), ffi.fptr(out["t"]),
-                                          ffi.fptr(out["normal"]), ffi.fptr(out["uv"]), ffi.bptr(out["front"])))
+        ffi.check(rec.fn("rt_trace_rays")(self.handle, rec.ptr(rays), n, float(F(t_min)), float(F(t_max)), seed,
+                                          ffi.iptr(out["prim_id"]), ffi.iptr(out["sub_id"]), rec.ptr(out["t"]),
+                                          rec.ptr(out["normal"]), rec.ptr(out["uv"]), ffi.bptr(out["front"])))
         return out
 
     def trace_paths(self, camera, pattern, background, width, height, ids, max_depth=50, seed=DEFAULT_SEED):
-        pat, n = _pattern(pattern)
+        rec, F = self.rec, self.F
+        pat, n = _pattern(pattern, F)
         bg = np.asarray(background, dtype=F)
         ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(-1, 3)
         rad = np.zeros((ids.shape[0], 3), dtype=F)
-        cam = camera_record(camera)
-        ffi.check(ffi.lib().rt_trace_paths(self.handle, C.byref(cam), ffi.fptr(pat), n, ffi.fptr(bg), width, height,
-                                           max_depth, seed, ffi.iptr(ids), ids.shape[0], ffi.fptr(rad)))
+        cam = camera_record(camera, rec)
+        ffi.check(rec.fn("rt_trace_paths")(self.handle, C.byref(cam), rec.ptr(pat), n, rec.ptr(bg), width, height,
+                                           max_depth, seed, ffi.iptr(ids), ids.shape[0], rec.ptr(rad)))
         return rad
 
 
@@ -285,10 +306,18 @@ class DeviceGroup:
 
 
 def render(world, material=None, *, width=None, height=None, camera=None, background=None, pattern=None,
-           gpu=False, spp=None, seed=DEFAULT_SEED, device=0, devices=None, **kwargs):
+           gpu=False, spp=None, seed=DEFAULT_SEED, device=0, devices=None, F=np.float32, **kwargs):
     """render(world::Vector{<:Hittable}; ...), render(filename, material; ...) and render(key::Symbol; ...)
     (main.jl:21-96).  Defaults as main.jl:22-27: 1280x720, Camera(), sky-blue background, MSAA_S16.
-    Returns an (height, width, 3) float32 image, row 0 = top, sqrt-gamma, unclamped."""
+    F is the reference's leading type argument (render(Float64, ...), main.jl:21,46): numpy.float32 or numpy.float64.
+    Returns an (height, width, 3) image of that type, row 0 = top, sqrt-gamma, unclamped."""
+    F = ffi.records(F).np_type
+    with H.element_type(F):
+        return _render(world, material, width, height, camera, background, pattern, gpu, spp, seed, device, devices)
+
+
+def _render(world, material, width, height, camera, background, pattern, gpu, spp, seed, device, devices):
+    F = H.F
     given = {k: v for k, v in dict(width=width, height=height, camera=camera, background=background,
                                    pattern=pattern).items() if v is not None}
     opts = dict(width=1280, height=720, camera=None, background=(0.70, 0.80, 1.00), pattern=None)
@@ -299,7 +328,7 @@ def render(world, material=None, *, width=None, height=None, camera=None, backgr
     elif isinstance(world, str):
         # render(key::Symbol; gpu, kwargs...) (main.jl:90-94): scene values, overridden by the caller's kwargs
         from .scenes import get_scene
-        world, scene_kwargs = get_scene(world, **({} if spp is None else {"spp": spp}))
+        world, scene_kwargs = get_scene(world, F=F, **({} if spp is None else {"spp": spp}))
         opts.update(scene_kwargs)
     opts.update(given)
     if opts["camera"] is None:
@@ -311,9 +340,11 @@ def render(world, material=None, *, width=None, height=None, camera=None, backgr
                                   "the MI355X path (gpu=True)")
     # devices: a list of GPUs to spread the samples over (rt_group_*), "all" = every visible GPU; default: the one `device`
     if devices is not None:
+        if F is not np.float32:
+            raise NotImplementedError("rt_group_* (several GPUs in one process) exists for Float32 only")
         scene = DeviceGroup(world, devices=None if isinstance(devices, str) and devices == "all" else devices)
     else:
-        scene = DeviceScene(world, device=device)
+        scene = DeviceScene(world, device=device, F=F)
     try:
         img, _ = scene.render(opts["camera"], opts["pattern"], opts["background"], opts["width"], opts["height"],
                               seed=seed)

@@ -10,7 +10,6 @@ import numpy as np
 from . import _ffi as ffi
 from . import hittables as H
 
-F = np.float32
 
 
 # --------------------------------------------------------------------- type keys
@@ -72,7 +71,8 @@ def build_bvh(objects):
     """build_bvh(objects::Vector{<:Hittable}) (src/BVH.jl:98-109) and build_bvh(meshes::Vector{<:Mesh})
     (src/mesh.jl:294-305), executed by the library's restated builders."""
     objects = list(objects)
-    L = ffi.lib()
+    rec = ffi.records(H.F)  # the element type picks the builder: rt_bvh_build or rt_bvh_build_f64
+    F = rec.np_type
     n = len(objects)
     if n == 0:
         raise ValueError("build_bvh: empty object list")
@@ -83,7 +83,8 @@ def build_bvh(objects):
         nt = np.array([o.indices.shape[0] for o in objects], dtype=np.int32)
         idx = [o.indices.copy() for o in objects]
         tri = [np.zeros(o.indices.shape[0], dtype=np.int32) for o in objects]
-        vptr = (ffi.c_f32p * n)(*[ffi.fptr(o.vertices) for o in objects])
+        verts = [np.ascontiguousarray(o.vertices, dtype=F) for o in objects]
+        vptr = (rec.real_p * n)(*[rec.ptr(v) for v in verts])
         iptr = (ffi.c_i32p * n)(*[ffi.iptr(a) for a in idx])
         tptr = (ffi.c_i32p * n)(*[ffi.iptr(a) for a in tri])
         order = np.zeros(n, dtype=np.int32)
@@ -91,8 +92,8 @@ def build_bvh(objects):
         nl = np.zeros(slots, dtype=np.int32)
         nr = np.zeros(slots, dtype=np.int32)
         lf = np.zeros(slots, dtype=np.uint8)
-        ffi.check(L.rt_bvh_build_meshes(n, ffi.iptr(nv), vptr, ffi.iptr(nt), iptr, tptr, ffi.iptr(order),
-                                        ffi.fptr(nb), ffi.iptr(nl), ffi.iptr(nr), ffi.bptr(lf)))
+        ffi.check(rec.fn("rt_bvh_build_meshes")(n, ffi.iptr(nv), vptr, ffi.iptr(nt), iptr, tptr, ffi.iptr(order),
+                                                rec.ptr(nb), ffi.iptr(nl), ffi.iptr(nr), ffi.bptr(lf)))
         md = {id(o): (idx[i], tri[i]) for i, o in enumerate(objects)}
         return BVHTree(1, [objects[i] for i in order], objects, nb, nl, nr, lf, md)
     bounds = np.stack([H.bounding_box(o).as6() for o in objects]).astype(F)
@@ -102,8 +103,8 @@ def build_bvh(objects):
     nl = np.zeros(slots, dtype=np.int32)
     nr = np.zeros(slots, dtype=np.int32)
     lf = np.zeros(slots, dtype=np.uint8)
-    ffi.check(L.rt_bvh_build(n, ffi.fptr(bounds), ffi.iptr(order), ffi.fptr(nb), ffi.iptr(nl), ffi.iptr(nr),
-                             ffi.bptr(lf)))
+    ffi.check(rec.fn("rt_bvh_build")(n, rec.ptr(bounds), ffi.iptr(order), rec.ptr(nb), ffi.iptr(nl), ffi.iptr(nr),
+                                     ffi.bptr(lf)))
     return BVHTree(0, [objects[i] for i in order], objects, nb, nl, nr, lf)
 
 
@@ -117,7 +118,8 @@ class Flattener:
     """Collects the record tables of include/rt_amd.h from a hittable tree.  Used for the device scene
     description (trees included) and, by the tests, for the plain world list given to the checker."""
 
-    def __init__(self):
+    def __init__(self, rec=None):
+        self.rec = rec or ffi.records(H.F)  # record types of the element type (float or double fields)
         self.objects, self.obj_index = [], {}
         self.transforms, self.materials, self.mat_index = [], [], {}
         self.textures, self.tex_index = [], {}
@@ -130,7 +132,7 @@ class Flattener:
     def texture(self, tex):
         if id(tex) in self.tex_index:
             return self.tex_index[id(tex)]
-        t = ffi.rtTexture()
+        t = self.rec.rtTexture()
         if isinstance(tex, H.SolidColor):
             t.kind = ffi.RT_TEX_SOLID
             t.color[:] = [float(x) for x in tex.color]
@@ -149,7 +151,7 @@ class Flattener:
             t.kind = ffi.RT_TEX_NOISE_MARBLE if tex.vector else ffi.RT_TEX_NOISE_SCALAR
             t.scale = tex.scale
             if id(tex.noise) not in self.perlin_index:
-                p = ffi.rtPerlin()
+                p = self.rec.rtPerlin()
                 p.ranvec[:] = [float(x) for x in tex.noise.random.reshape(-1)]
                 p.perm_x[:] = tex.noise.perm_x
                 p.perm_y[:] = tex.noise.perm_y
@@ -167,7 +169,7 @@ class Flattener:
     def material(self, mat):
         if id(mat) in self.mat_index:
             return self.mat_index[id(mat)]
-        m = ffi.rtMaterial(mat.type, self.texture(mat.albedo), float(mat.fuzz), float(mat.eta))
+        m = self.rec.rtMaterial(mat.type, self.texture(mat.albedo), float(mat.fuzz), float(mat.eta))
         self.materials.append(m)
         self.mat_index[id(mat)] = len(self.materials) - 1
         self.keep.append(mat)
@@ -176,7 +178,7 @@ class Flattener:
     def obj(self, o, with_trees):
         if id(o) in self.obj_index:
             return self.obj_index[id(o)]
-        r = ffi.rtObject()
+        r = self.rec.rtObject()
         r.material, r.child, r.aux = -1, -1, -1
         if isinstance(o, H.Sphere):
             r.kind, r.material = ffi.RT_SPHERE, self.material(o.material)
@@ -194,7 +196,7 @@ class Flattener:
         elif isinstance(o, H.Transform):
             r.kind = ffi.RT_TRANSFORM
             r.child = self.obj(o.object, with_trees)
-            t = ffi.rtTransform()
+            t = self.rec.rtTransform()
             t.xform[:] = [float(x) for x in o.xform]
             t.inv_xform[:] = [float(x) for x in o.inv_xform]
             t.bbox[:] = [float(x) for x in o.bbox.as6()]
@@ -233,37 +235,40 @@ class Flattener:
         return a
 
     def _bvh_record(self, tree):
-        b = ffi.rtBvh()
+        b = self.rec.rtBvh()
         b.kind = tree.kind
         objs = np.array([self.obj_index[id(o)] for o in tree.objects], dtype=np.int32)
         self.keep += [objs, tree]
         b.n_objects, b.objects = len(objs), ffi.iptr(objs)
         b.n_nodes = tree.node_bounds.shape[0]
-        b.node_bounds = ffi.fptr(tree.node_bounds)
+        bounds = np.ascontiguousarray(tree.node_bounds, dtype=self.rec.np_type)
+        self.keep.append(bounds)
+        b.node_bounds = self.rec.ptr(bounds)
         b.node_left, b.node_right = ffi.iptr(tree.node_left), ffi.iptr(tree.node_right)
         b.node_leaf = ffi.bptr(tree.node_leaf)
         return b
 
     def _mesh_record(self, mesh, sorted_data):
-        m = ffi.rtMesh()
+        m = self.rec.rtMesh()
         m.n_vertices, m.n_triangles, m.n_materials = mesh.vertices.shape[0], mesh.indices.shape[0], len(mesh.materials)
         mats = np.array([self.material(x) for x in mesh.materials], dtype=np.int32)
         idx, tri = sorted_data if sorted_data is not None else (mesh.indices, None)
-        self.keep += [mats, idx, tri, mesh.vertices]
-        m.vertices, m.indices, m.materials = ffi.fptr(mesh.vertices), ffi.iptr(idx), ffi.iptr(mats)
+        verts = np.ascontiguousarray(mesh.vertices, dtype=self.rec.np_type)
+        self.keep += [mats, idx, tri, verts]
+        m.vertices, m.indices, m.materials = self.rec.ptr(verts), ffi.iptr(idx), ffi.iptr(mats)
         m.tri_ids = ffi.iptr(tri) if tri is not None else None
         return m
 
     def common_tables(self, desc, mesh_sorted=None):
         mesh_sorted = mesh_sorted or {}
-        desc.n_objects, desc.objects = len(self.objects), self._arr(ffi.rtObject, self.objects)
-        desc.n_transforms, desc.transforms = len(self.transforms), self._arr(ffi.rtTransform, self.transforms)
+        desc.n_objects, desc.objects = len(self.objects), self._arr(self.rec.rtObject, self.objects)
+        desc.n_transforms, desc.transforms = len(self.transforms), self._arr(self.rec.rtTransform, self.transforms)
         mesh_records = [self._mesh_record(m, mesh_sorted.get(id(m))) for m in self.meshes]
-        desc.n_meshes, desc.meshes = len(mesh_records), self._arr(ffi.rtMesh, mesh_records)
-        desc.n_materials, desc.materials = len(self.materials), self._arr(ffi.rtMaterial, self.materials)
-        desc.n_textures, desc.textures = len(self.textures), self._arr(ffi.rtTexture, self.textures)
+        desc.n_meshes, desc.meshes = len(mesh_records), self._arr(self.rec.rtMesh, mesh_records)
+        desc.n_materials, desc.materials = len(self.materials), self._arr(self.rec.rtMaterial, self.materials)
+        desc.n_textures, desc.textures = len(self.textures), self._arr(self.rec.rtTexture, self.textures)
         desc.n_images, desc.images = len(self.images), self._arr(ffi.rtImage, self.images)
-        desc.n_perlins, desc.perlins = len(self.perlins), self._arr(ffi.rtPerlin, self.perlins)
+        desc.n_perlins, desc.perlins = len(self.perlins), self._arr(self.rec.rtPerlin, self.perlins)
 
 
 def flatten_scene(world, bvh):
@@ -271,7 +276,7 @@ def flatten_scene(world, bvh):
     per-type trees built from SceneManager(world)."""
     fl = Flattener()
     top = np.array([fl.obj(o, True) for o in world], dtype=np.int32)
-    desc = ffi.rtSceneDesc()
+    desc = fl.rec.rtSceneDesc()
     mesh_sorted = {}
     for tree in bvh:
         mesh_sorted.update(tree.mesh_data)
@@ -279,7 +284,7 @@ def flatten_scene(world, bvh):
     desc.n_top, desc.top = len(top), ffi.iptr(top)
     groups = [fl._bvh_record(g) for g in fl.groups]
     buckets = [fl._bvh_record(t) for t in bvh]
-    desc.n_groups, desc.groups = len(groups), fl._arr(ffi.rtBvh, groups)
-    desc.n_buckets, desc.buckets = len(buckets), fl._arr(ffi.rtBvh, buckets)
+    desc.n_groups, desc.groups = len(groups), fl._arr(fl.rec.rtBvh, groups)
+    desc.n_buckets, desc.buckets = len(buckets), fl._arr(fl.rec.rtBvh, buckets)
     fl.keep.append(top)
     return desc, fl

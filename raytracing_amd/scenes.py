@@ -13,7 +13,6 @@ from .hittables import (Box, Camera, ConstantMedium, Dielectric, Emissive, Halto
                         Lambertian, Material, Metal, MovingSphere, NoiseTexture, RotY, Sphere, Transform, Vec3,
                         affine, hfov_from_vfov, xy_rect, xz_rect, yz_rect)
 
-F = np.float32
 M32 = 0xFFFFFFFF
 
 
@@ -36,8 +35,10 @@ class SceneRng:
                 v = [x ^ (x >> 16) for x in v]
         return v[0]
 
-    def rand32(self):  # rand(Float32)
-        return F(self._u32() >> 8) * F(1.0 / 16777216.0)
+    def rand32(self):  # rand(F): 24 bits for Float32, 53 for Float64
+        if H.F is np.float64:
+            return self.rand64()
+        return np.float32(self._u32() >> 8) * np.float32(1.0 / 16777216.0)
 
     def rand64(self):  # rand()
         return ((self._u32() >> 5) * 67108864.0 + (self._u32() >> 6)) / 9007199254740992.0
@@ -46,7 +47,7 @@ class SceneRng:
         return Vec3(self.rand32(), self.rand32(), self.rand32())
 
     def rand_vec3_range(self, lo, hi):  # rand(Vec3{F}, min, max), src/vec3.jl:85
-        lo, hi = F(lo), F(hi)
+        lo, hi = H.F(lo), H.F(hi)
         return Vec3(*[self.rand32() * (hi - lo) + lo for _ in range(3)])
 
     def shuffle(self, items):
@@ -113,7 +114,7 @@ def cornell_smoke_box(spp=200, **_):
 def cover1(spp=500, seed=1, **_):
     """samples/cover_in_one_weekend.jl"""
     rng = SceneRng(seed)
-    aspect_ratio = F(3 / 2)
+    aspect_ratio = H.F(3 / 2)
     width = 1200
     height = int(width / aspect_ratio)
     origin, target = Vec3(13, 2, 3), Vec3(0, 0, 0)
@@ -124,12 +125,12 @@ def cover1(spp=500, seed=1, **_):
         for b in range(-11, 11):
             choose_mat = rng.rand32()
             center = Vec3(a + 0.9 * rng.rand64(), 0.2, b + 0.9 * rng.rand64())
-            if H.length(center - Vec3(4, 0.2, 0)) > F(0.9):
+            if H.length(center - Vec3(4, 0.2, 0)) > H.F(0.9):
                 if choose_mat < 0.8:
                     material = Material(Lambertian, rng.rand_vec3() * rng.rand_vec3())
                 elif choose_mat < 0.95:
-                    albedo = rng.rand_vec3() * F(0.5) + F(0.5)
-                    material = Material(Metal, albedo, rng.rand32() * F(0.5))
+                    albedo = rng.rand_vec3() * H.F(0.5) + H.F(0.5)
+                    material = Material(Metal, albedo, rng.rand32() * H.F(0.5))
                 else:
                     material = Material(Dielectric, 1.5)
                 world.append(Sphere(center, 0.2, material))
@@ -156,7 +157,7 @@ def _next_week(spp, seed, full):
             w = 100
             x0, z0, y0 = -1000 + i * w, -1000 + j * w, 0
             x1, z1 = x0 + w, z0 + w
-            y1 = rng.rand32() * F(79) + F(1)
+            y1 = rng.rand32() * H.F(79) + H.F(1)
             boxes.append(Box(Vec3(x0, y0, z0), Vec3(x1, y1, z1), ground))
     objects = []
     center1 = Vec3(400, 400, 200)
@@ -217,10 +218,11 @@ scenes = {
 extra_scenes = {"teapot": teapot}
 
 
-def get_scene(key, **kwargs):
-    """scenes.jl:8-11"""
+def get_scene(key, F=None, **kwargs):
+    """scenes.jl:8-11; F = the element type the scene function is given (samples/cornell_box.jl:3: F::Type=Float32)"""
     fn = scenes.get(key) or extra_scenes[key]
-    width, height, camera, world, background, pattern = fn(**kwargs)
+    with H.element_type(F if F is not None else H.F):
+        width, height, camera, world, background, pattern = fn(**kwargs)
     return world, dict(width=width, height=height, camera=camera, background=background, pattern=pattern)
 
 

@@ -1,0 +1,145 @@
+"""The Float64 mode (render(Float64, ...), main.jl:21,46) against the oracle built for Float64 (oracle/rt_ref.cpp with
+-DREF_F64): closest hits of fixed rays, per-path radiance and whole images must be identical in every bit of every
+double -- the device walks the reference's own trees with the reference's own box test, so nothing is tolerated.
+Through the C ABI (rt_scene_create_f64, rt_render_f64, rt_render_accumulate_f64, rt_finalize_f64, rt_trace_rays_f64,
+rt_trace_paths_f64)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import raytracing_amd as rt
+from raytracing_amd import hittables as H
+
+pytestmark = pytest.mark.gpu
+F = np.float64
+SCENES = ["cornell_box", "cornell_smoke_box", "cover1", "cu_cover2", "cover2", "teapot"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=F).view(np.uint64)
+
+
+def same_hits(a, b):
+    same = (a["prim_id"] == b["prim_id"]) & (a["sub_id"] == b["sub_id"]) & (bits(a["t"]) == bits(b["t"]))
+    assert same.all(), np.flatnonzero(~same)[:10]
+    for field in ("normal", "uv"):
+        np.testing.assert_array_equal(bits(a[field]), bits(b[field]))
+    np.testing.assert_array_equal(a["front"], b["front"])
+
+
+@pytest.mark.parametrize("key", SCENES)
+def test_sample_scene_hits_paths_and_image(key):
+    world, kw = rt.get_scene(key, spp=5, F=F)
+    cam, pat, bg = kw["camera"], kw["pattern"], kw["background"]
+    assert pat.dtype == F and cam.origin.dtype == F
+    W, Hh = 56, 40
+    ref = O.OracleScene(world, F=F)
+    dev = rt.DeviceScene(world, F=F)
+    try:
+        rays = O.primary_rays(cam, W, Hh, 64, 48, time=0.37, F=F)
+        a = ref.trace_rays(rays)
+        same_hits(a, dev.trace_rays(rays))
+        assert (a["prim_id"] >= 0).any()
+        # secondary rays from just in front of the first hits, in random directions
+        g = np.random.default_rng(7)
+        pts = rays[:, :3] + rays[:, 3:6] * np.where(np.isfinite(a["t"]), a["t"] * 0.95, 1.0)[:, None]
+        sec = np.concatenate([pts, g.normal(size=(len(rays), 3)), g.uniform(0, 1, (len(rays), 1))], axis=1).astype(F)
+        same_hits(ref.trace_rays(sec), dev.trace_rays(sec))
+        ids = np.stack([g.integers(0, W, 600), g.integers(0, Hh, 600), g.integers(0, 5, 600)], axis=1).astype(np.int32)
+        np.testing.assert_array_equal(bits(ref.trace_paths(cam, pat, bg, W, Hh, ids)), bits(dev.trace_paths(cam, pat, bg, W, Hh, ids)))
+        img, st = dev.render(cam, pat, bg, W, Hh)
+        assert img.dtype == F and st.paths == W * Hh * 5
+        want = ref.render(cam, pat, bg, W, Hh)
+        assert (bits(img) != bits(want)).sum() == 0
+        assert np.isfinite(img[np.isfinite(want)]).all()
+    finally:
+        dev.close()
+
+
+def test_float64_differs_from_float32_only_by_rounding_at_the_first_hit():
+    """The two element types see the same scene: first hits agree in id, and in t to Float32 accuracy."""
+    w32, kw32 = rt.get_scene("cornell_box", spp=1)
+    w64, kw64 = rt.get_scene("cornell_box", spp=1, F=F)
+    d32, d64 = rt.DeviceScene(w32), rt.DeviceScene(w64, F=F)
+    try:
+        r64 = O.primary_rays(kw64["camera"], 400, 400, 40, 40, F=F)
+        a, b = d32.trace_rays(r64.astype(np.float32)), d64.trace_rays(r64)
+        agree = a["prim_id"] == b["prim_id"]
+        assert agree.mean() > 0.99
+        hit = agree & (b["prim_id"] >= 0)
+        np.testing.assert_allclose(a["t"][hit], b["t"][hit], rtol=2e-5)
+    finally:
+        d32.close()
+        d64.close()
+
+
+def test_batches_and_shards_sum_like_one_frame(monkeypatch):
+    """Columns traced in several batches (radiance buffer smaller than the frame) give the same picture bit for bit;
+    two interleaved shards (rt_render_accumulate_f64 twice, summed, rt_finalize_f64) give it up to the order of the
+    sums."""
+    import torch
+    world, kw = rt.get_scene("cornell_smoke_box", spp=7, F=F)
+    cam, pat, bg = kw["camera"], kw["pattern"], kw["background"]
+    W, Hh = 48, 36
+    dev = rt.DeviceScene(world, F=F)
+    try:
+        whole, _ = dev.render(cam, pat, bg, W, Hh)
+        monkeypatch.setenv("RT_AMD_F64_BATCH_COLUMNS", "3")
+        again, _ = dev.render(cam, pat, bg, W, Hh)
+        monkeypatch.delenv("RT_AMD_F64_BATCH_COLUMNS")
+        assert (bits(whole) != bits(again)).sum() == 0
+        parts = [torch.empty(3 * W * Hh, dtype=torch.float64, device="cuda") for _ in range(3)]
+        stream = torch.cuda.current_stream().cuda_stream
+        for c in range(3):  # the third shard is empty for c >= n: here n = 7, shards 0, 1, 2 of 3
+            dev.accumulate(cam, pat, bg, W, Hh, parts[c].data_ptr(), sample_first=c, sample_stride=3, stream=stream)
+        total = parts[0] + parts[1] + parts[2]
+        out = torch.empty_like(total)
+        dev.finalize(total.data_ptr(), 7, W, Hh, out.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        img = out.cpu().numpy().reshape(W, Hh, 3).transpose(1, 0, 2)
+        np.testing.assert_allclose(img, whole, rtol=1e-13, atol=1e-300)
+        empty = torch.full((3 * W * Hh,), 5.0, dtype=torch.float64, device="cuda")
+        dev.accumulate(cam, pat, bg, W, Hh, empty.data_ptr(), sample_first=9, sample_stride=3, stream=stream)
+        torch.cuda.synchronize()
+        assert float(empty.abs().max()) == 0.0
+    finally:
+        dev.close()
+
+
+def test_bad_arguments_are_errors():
+    from raytracing_amd import _ffi as ffi
+    world, kw = rt.get_scene("cornell_box", spp=2, F=F)
+    dev = rt.DeviceScene(world, F=F)
+    try:
+        with pytest.raises(ffi.RtError):
+            dev.render(kw["camera"], kw["pattern"], kw["background"], 1, 1)
+        with pytest.raises(ffi.RtError):
+            dev.trace_paths(kw["camera"], kw["pattern"], kw["background"], 8, 8, [[9, 0, 0]])
+        with pytest.raises(ffi.RtError):
+            dev.layout()
+    finally:
+        dev.close()
+    with pytest.raises(ffi.RtError):  # Transform{Transform}: the nestings the Float32 path turns down
+        inner = rt.Transform(rt.Sphere(rt.Vec3(0), 1.0, rt.Material(rt.Lambertian, rt.Vec3(0.5))), np.eye(4))
+        rt.DeviceScene([rt.Transform(inner, np.eye(4))], F=F)
+
+
+# RT_AMD_FUZZ_SCENES_F64=N changes the size of the sweep
+@pytest.mark.parametrize("seed", range(1, 1 + int(os.environ.get("RT_AMD_FUZZ_SCENES_F64", "150"))))
+def test_random_scene_f64(seed):
+    from test_gpu_fuzz import random_scene
+    with H.element_type(F):
+        world, cam, bg = random_scene(seed)
+        pat = rt.Halton_sequence32(4)
+    W, Hh = 32, 24
+    ref = O.OracleScene(world, F=F)
+    dev = rt.DeviceScene(world, F=F)
+    try:
+        rays = O.primary_rays(cam, W, Hh, 40, 32, time=0.37, F=F)
+        same_hits(ref.trace_rays(rays), dev.trace_rays(rays))
+        img, _ = dev.render(cam, pat, bg, W, Hh)
+        assert (bits(img) != bits(ref.render(cam, pat, bg, W, Hh))).sum() == 0
+    finally:
+        dev.close()
