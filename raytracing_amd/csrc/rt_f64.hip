@@ -33,6 +33,9 @@ typedef double real;
 #define R64_INF (__builtin_inf())
 #define R64_BLOCK 128
 #define R64_STACK 48
+#ifndef R64_WAVES
+#define R64_WAVES 3 // waves per SIMD the path kernel is compiled for (registers per lane: 512 / R64_WAVES)
+#endif
 
 #define HIP_TRY64(expr)                                                                                   \
     do {                                                                                                  \
@@ -75,7 +78,9 @@ struct Scene64 {
     const Node64* nodes;
     const int32_t* tree_objects;
     const Tree64* trees;       // the type groups of the SceneManager in order, then the nested trees
+    const uint8_t* mat_uv;     // per material: 1 if its texture can read (u, v) (an image texture, possibly through checkers)
     int32_t n_buckets, n_groups;
+    int32_t all_uv, pad;       // 1: every hit carries its (u, v) (the parity hook reports them); 0: only where a texture reads them
 };
 struct Frame64 {
     rtCamera64 cam;
@@ -294,6 +299,43 @@ __device__ inline bool hit_aabb(const real* b, const Ray& r, real t_min, real t_
     return true;
 }
 
+// The same decision from reciprocal distances, where that is certain.  The box test only decides which subtrees are
+// walked, so all that matters is its outcome: with inv = 1 / d rounded once per ray, (b - o) * inv differs from the
+// reference's (b - o) / d by less than 3.2 ulp, the minima and maxima of such values keep that bound, and a
+// comparison of two of them has the reference's outcome whenever they are further apart than 2^-50 of their
+// magnitudes.  Every one of the reference's three `t_max <= t_min` decisions is taken that way; the first that is
+// not certain (grazing rays, infinities and NaNs of axis-parallel rays) hands the whole test to the divisions above.
+// Six IEEE double divisions per node become six multiplications.
+__device__ inline bool hit_aabb_fast(const real* b, const Ray& r, const V3& inv, real t_min0, real t_max0) {
+    const real TOL = 8.881784197001252e-16; // 2^-50
+    real t_min = t_min0, t_max = t_max0;
+    real lo = (b[0] - r.o.x) * inv.x, hi = (b[3] - r.o.x) * inv.x;
+    if (lo > hi) { real s = lo; lo = hi; hi = s; }
+    if (hi < t_max) t_max = hi;
+    if (lo > t_min) t_min = lo;
+    real gap = t_max - t_min, tol = TOL * (fabs(t_max) + fabs(t_min)) + 1e-300;
+    if (gap < -tol) return false;
+    if (!(gap > tol)) return hit_aabb(b, r, t_min0, t_max0);
+
+    lo = (b[1] - r.o.y) * inv.y; hi = (b[4] - r.o.y) * inv.y;
+    if (lo > hi) { real s = lo; lo = hi; hi = s; }
+    if (hi < t_max) t_max = hi;
+    if (lo > t_min) t_min = lo;
+    gap = t_max - t_min; tol = TOL * (fabs(t_max) + fabs(t_min)) + 1e-300;
+    if (gap < -tol) return false;
+    if (!(gap > tol)) return hit_aabb(b, r, t_min0, t_max0);
+
+    lo = (b[2] - r.o.z) * inv.z; hi = (b[5] - r.o.z) * inv.z;
+    if (lo > hi) { real s = lo; lo = hi; hi = s; }
+    if (hi < t_max) t_max = hi;
+    if (lo > t_min) t_min = lo;
+    gap = t_max - t_min; tol = TOL * (fabs(t_max) + fabs(t_min)) + 1e-300;
+    if (gap < -tol) return false;
+    if (!(gap > tol)) return hit_aabb(b, r, t_min0, t_max0);
+    return true;
+}
+__device__ inline V3 reciprocal(V3 d) { return v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
+
 // ------------------------------------------------------------------ primitives
 __device__ inline void get_sphere_uv(V3 p, real& u, real& v) { // src/sphere.jl:104-108
     const real PI = 3.14159265358979323846;
@@ -305,7 +347,9 @@ __device__ inline void get_sphere_uv(V3 p, real& u, real& v) { // src/sphere.jl:
     u = phi / TWO_PI;
     v = theta / PI;
 }
-__device__ Hit hit_sphere(V3 center, real radius, int material, const Ray& r, real t_min, real t_max) { // src/sphere.jl:45-102
+// want_uv: the reference computes (u, v) -- an acos and an atan -- for every candidate hit; nothing but an image texture
+// reads them, so the render kernels leave them 0 for every other material (radiance unchanged), the hook asks for all
+__device__ Hit hit_sphere(V3 center, real radius, int material, const Ray& r, real t_min, real t_max, bool want_uv) { // src/sphere.jl:45-102
     V3 oc = r.o - center;
     real a = dot(r.d, r.d);
     real half_b = dot(oc, r.d);
@@ -324,13 +368,13 @@ __device__ Hit hit_sphere(V3 center, real radius, int material, const Ray& r, re
     h.p = at(r, root);
     V3 normal = div_real(h.p - center, radius);
     h.front = dot(r.d, normal) < 0.0;
-    get_sphere_uv(normal, h.u, h.v);
+    if (want_uv) get_sphere_uv(normal, h.u, h.v);
     h.n = (real)(-1 + ((int)h.front << 1)) * normal;
     h.material = material;
     return h;
 }
 // src/aarect.jl:49-119; axis = the constant axis (2: xy_rect, 1: xz_rect, 0: yz_rect)
-__device__ Hit hit_rect(int axis, real a0, real a1, real b0, real b1, real k, int material, const Ray& r, real t_min, real t_max) {
+__device__ Hit hit_rect(int axis, real a0, real a1, real b0, real b1, real k, int material, const Ray& r, real t_min, real t_max, bool want_uv) {
     real ok, dk, oa, da, ob, db;
     if (axis == 2) { ok = r.o.z; dk = r.d.z; oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
     else if (axis == 1) { ok = r.o.y; dk = r.d.y; oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
@@ -347,23 +391,25 @@ __device__ Hit hit_rect(int axis, real a0, real a1, real b0, real b1, real k, in
     else h.p = v3(k, a, b);
     V3 normal = axis == 2 ? v3(0, 0, 1) : (axis == 1 ? v3(0, 1, 0) : v3(1, 0, 0));
     h.front = dot(r.d, normal) < 0.0;
-    h.u = (a - a0) / (a1 - a0);
-    h.v = (b - b0) / (b1 - b0);
+    if (want_uv) {
+        h.u = (a - a0) / (a1 - a0);
+        h.v = (b - b0) / (b1 - b0);
+    }
     h.n = (real)(-1 + 2 * (int)h.front) * normal;
     h.material = material;
     return h;
 }
-__device__ Hit hit_box(const real* p, int material, const Ray& r, real t_min, real t_max) { // src/box.jl:9-24,43-83
+__device__ Hit hit_box(const real* p, int material, const Ray& r, real t_min, real t_max, bool want_uv) { // src/box.jl:9-24,43-83
     Hit closest = miss();
     for (int s = 0; s < 6; ++s) {
         Hit h;
         switch (s) {
-            case 0: h = hit_rect(2, p[0], p[3], p[1], p[4], p[5], material, r, t_min, t_max); break;
-            case 1: h = hit_rect(2, p[0], p[3], p[1], p[4], p[2], material, r, t_min, t_max); break;
-            case 2: h = hit_rect(1, p[0], p[3], p[2], p[5], p[4], material, r, t_min, t_max); break;
-            case 3: h = hit_rect(1, p[0], p[3], p[2], p[5], p[1], material, r, t_min, t_max); break;
-            case 4: h = hit_rect(0, p[1], p[4], p[2], p[5], p[3], material, r, t_min, t_max); break;
-            default: h = hit_rect(0, p[1], p[4], p[2], p[5], p[0], material, r, t_min, t_max); break;
+            case 0: h = hit_rect(2, p[0], p[3], p[1], p[4], p[5], material, r, t_min, t_max, want_uv); break;
+            case 1: h = hit_rect(2, p[0], p[3], p[1], p[4], p[2], material, r, t_min, t_max, want_uv); break;
+            case 2: h = hit_rect(1, p[0], p[3], p[2], p[5], p[4], material, r, t_min, t_max, want_uv); break;
+            case 3: h = hit_rect(1, p[0], p[3], p[2], p[5], p[1], material, r, t_min, t_max, want_uv); break;
+            case 4: h = hit_rect(0, p[1], p[4], p[2], p[5], p[3], material, r, t_min, t_max, want_uv); break;
+            default: h = hit_rect(0, p[1], p[4], p[2], p[5], p[0], material, r, t_min, t_max, want_uv); break;
         }
         if (h.t < closest.t) {
             closest = h;
@@ -374,19 +420,20 @@ __device__ Hit hit_box(const real* p, int material, const Ray& r, real t_min, re
     return closest;
 }
 // Sphere, MovingSphere, the three rectangles, Box
-__device__ Hit hit_basic(const rtObject64& o, const Ray& r, real t_min, real t_max) {
+__device__ Hit hit_basic(const Scene64& S, const rtObject64& o, const Ray& r, real t_min, real t_max) {
     const real* p = o.p;
+    const bool want_uv = S.all_uv || S.mat_uv[o.material];
     switch (o.kind) {
-        case RT_SPHERE: return hit_sphere(v3(p[0], p[1], p[2]), p[3], o.material, r, t_min, t_max);
+        case RT_SPHERE: return hit_sphere(v3(p[0], p[1], p[2]), p[3], o.material, r, t_min, t_max, want_uv);
         case RT_MOVING_SPHERE: { // src/sphere.jl:24-26
             V3 c0 = v3(p[0], p[1], p[2]), c1 = v3(p[4], p[5], p[6]);
             V3 center = c0 + ((r.time - p[3]) / (p[7] - p[3])) * (c1 - c0);
-            return hit_sphere(center, p[8], o.material, r, t_min, t_max);
+            return hit_sphere(center, p[8], o.material, r, t_min, t_max, want_uv);
         }
-        case RT_XY_RECT: return hit_rect(2, p[0], p[1], p[2], p[3], p[4], o.material, r, t_min, t_max);
-        case RT_XZ_RECT: return hit_rect(1, p[0], p[1], p[2], p[3], p[4], o.material, r, t_min, t_max);
-        case RT_YZ_RECT: return hit_rect(0, p[0], p[1], p[2], p[3], p[4], o.material, r, t_min, t_max);
-        case RT_BOX: return hit_box(p, o.material, r, t_min, t_max);
+        case RT_XY_RECT: return hit_rect(2, p[0], p[1], p[2], p[3], p[4], o.material, r, t_min, t_max, want_uv);
+        case RT_XZ_RECT: return hit_rect(1, p[0], p[1], p[2], p[3], p[4], o.material, r, t_min, t_max, want_uv);
+        case RT_YZ_RECT: return hit_rect(0, p[0], p[1], p[2], p[3], p[4], o.material, r, t_min, t_max, want_uv);
+        case RT_BOX: return hit_box(p, o.material, r, t_min, t_max, want_uv);
     }
     return miss();
 }
@@ -401,13 +448,13 @@ __device__ inline V3 apply_vec(const real* T, V3 v) {
 // a basic object, or one inside a Transform (src/transform.jl:104-116)
 __device__ Hit hit_simple(const Scene64& S, int oi, const Ray& r, real t_min, real t_max) {
     const rtObject64& o = S.objects[oi];
-    if (o.kind != RT_TRANSFORM) return hit_basic(o, r, t_min, t_max);
+    if (o.kind != RT_TRANSFORM) return hit_basic(S, o, r, t_min, t_max);
     const rtTransform64& T = S.transforms[o.aux];
     Ray rr;
     rr.o = apply_point(T.inv_xform, r.o);
     rr.d = apply_vec(T.inv_xform, r.d);
     rr.time = r.time;
-    Hit h = hit_basic(S.objects[o.child], rr, t_min, t_max);
+    Hit h = hit_basic(S, S.objects[o.child], rr, t_min, t_max);
     if (h.t == R64_INF) return h;
     h.p = at(r, h.t);
     h.n = apply_vec(T.xform, h.n);
@@ -487,53 +534,84 @@ __device__ Hit hit_mesh_triangle(const Scene64& S, const Mesh64& m, int col, con
 }
 
 // ------------------------------------------------------------------ trees
+// While the trees are walked a hit is only what decides the walk: its distance, which object gave it and the bound
+// that object was tested with.  The record the reference builds for every candidate (point, normal, uv, material:
+// src/hit_record.jl) is built once, for the hit that is left at the end, by running that object's test again with the
+// same ray and the same bound (complete_hit): the same instructions on the same inputs, so the same bits.  It keeps a
+// walk's live state at a few registers per level of nesting instead of a full record each, which is what decides
+// how many waves a SIMD holds -- and the walk is bound by the latency of its node fetches, not by arithmetic.
+struct Lite {
+    real t;           // Inf: no hit
+    real bound;       // t_max of the test that found it
+    real inner_bound; // nested tree: t_max of the inner object's test
+    int32_t oi;       // the object of the walked tree (for a tree of meshes: the mesh)
+    int32_t inner;    // nested tree: the object inside it; tree of meshes: the column of the triangle (1-based)
+};
+__device__ inline Lite lite_miss() {
+    Lite l;
+    l.t = R64_INF; l.bound = R64_INF; l.inner_bound = R64_INF; l.oi = -1; l.inner = -1;
+    return l;
+}
+
 // stk: the calling lane's column of the stack in LDS (entry e at stk[e * R64_BLOCK]); sp0: entries already in use
 template <bool NESTED>
-__device__ Hit hit_tree(const Scene64& S, int tree, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp0);
+__device__ Lite hit_tree(const Scene64& S, int tree, const Ray& r, const V3& inv, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp0);
 
+// the ray in the frame of a Transform (src/transform.jl:105-107)
+__device__ inline Ray to_object_frame(const rtTransform64& T, const Ray& r) {
+    Ray rr;
+    rr.o = apply_point(T.inv_xform, r.o);
+    rr.d = apply_vec(T.inv_xform, r.d);
+    rr.time = r.time;
+    return rr;
+}
+
+// distance of the hit of object oi (Inf: none); for a nested tree also which object inside it and with what bound
 template <bool NESTED>
-__device__ Hit hit_object(const Scene64& S, int oi, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp) {
+__device__ inline real hit_object_t(const Scene64& S, int oi, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp,
+                                    int32_t& inner, real& inner_bound) {
     const rtObject64& o = S.objects[oi];
     if (!NESTED) {
-        if (o.kind == RT_CONSTANT_MEDIUM) return hit_medium(S, oi, r, t_min, t_max, c);
-        if (o.kind == RT_BVH) return hit_tree<true>(S, S.n_buckets + o.aux, r, t_min, t_max, c, stk, sp);
-        if (o.kind == RT_TRANSFORM && S.objects[o.child].kind == RT_BVH) {
-            const rtTransform64& T = S.transforms[o.aux];
-            Ray rr;
-            rr.o = apply_point(T.inv_xform, r.o);
-            rr.d = apply_vec(T.inv_xform, r.d);
-            rr.time = r.time;
-            Hit h = hit_tree<true>(S, S.n_buckets + S.objects[o.child].aux, rr, t_min, t_max, c, stk, sp);
-            if (h.t == R64_INF) return h;
-            h.p = at(r, h.t);
-            h.n = apply_vec(T.xform, h.n);
-            return h;
+        if (o.kind == RT_CONSTANT_MEDIUM) return hit_medium(S, oi, r, t_min, t_max, c).t;
+        const bool wrapped = o.kind == RT_TRANSFORM && S.objects[o.child].kind == RT_BVH;
+        if (o.kind == RT_BVH || wrapped) {
+            Lite l;
+            if (wrapped) {
+                Ray rr = to_object_frame(S.transforms[o.aux], r);
+                l = hit_tree<true>(S, S.n_buckets + S.objects[o.child].aux, rr, reciprocal(rr.d), t_min, t_max, c, stk, sp);
+            } else {
+                l = hit_tree<true>(S, S.n_buckets + o.aux, r, reciprocal(r.d), t_min, t_max, c, stk, sp);
+            }
+            inner = l.oi;
+            inner_bound = l.bound;
+            return l.t;
         }
     }
-    return hit_simple(S, oi, r, t_min, t_max);
+    return hit_simple(S, oi, r, t_min, t_max).t;
 }
 
 template <bool NESTED>
-__device__ Hit hit_tree(const Scene64& S, int tree, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp0) { // src/BVH.jl:22-53
+__device__ Lite hit_tree(const Scene64& S, int tree, const Ray& r, const V3& inv, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp0) { // src/BVH.jl:22-53
     const Tree64 T = S.trees[tree];
-    Hit closest = miss();
+    Lite closest = lite_miss();
     if (T.n_nodes == 0) return closest;
     int n = sp0;
     stk[(n++) * R64_BLOCK] = 1u;
     while (n > sp0) {
         const Node64& node = S.nodes[(size_t)T.node_base + stk[(--n) * R64_BLOCK] - 1u];
-        if (!hit_aabb(node.box, r, t_min, t_max)) continue;
+        if (!hit_aabb_fast(node.box, r, inv, t_min, t_max)) continue;
         if (node.leaf) {
             // src/hittable.jl:21-31 over objects[left:right]
-            Hit lh = miss();
+            Lite lh = lite_miss();
             real tm = t_max;
             for (int i = node.left; i <= node.right; ++i) {
                 int oi = S.tree_objects[T.obj_base + i - 1];
-                Hit h = hit_object<NESTED>(S, oi, r, t_min, tm, c, stk, n);
-                if (h.t < lh.t) {
-                    lh = h;
-                    if (NESTED) lh.sub = oi; else lh.prim = S.top_pos[oi];
-                    tm = lh.t;
+                int32_t inner = -1;
+                real inner_bound = R64_INF;
+                real t = hit_object_t<NESTED>(S, oi, r, t_min, tm, c, stk, n, inner, inner_bound);
+                if (t < lh.t) {
+                    lh.t = t; lh.bound = tm; lh.oi = oi; lh.inner = inner; lh.inner_bound = inner_bound;
+                    tm = t;
                 }
             }
             if (lh.t < closest.t) { t_max = lh.t; closest = lh; }
@@ -546,9 +624,9 @@ __device__ Hit hit_tree(const Scene64& S, int tree, const Ray& r, real t_min, re
 }
 
 // src/mesh.jl:115-163: the CPU walk of a tree over meshes (t_max is not narrowed)
-__device__ Hit hit_mesh_tree(const Scene64& S, int tree, const Ray& r, real t_min, real t_max, uint32_t* stk) {
+__device__ Lite hit_mesh_tree(const Scene64& S, int tree, const Ray& r, const V3& inv, real t_min, real t_max, uint32_t* stk) {
     const Tree64 T = S.trees[tree];
-    Hit closest = miss();
+    Lite closest = lite_miss();
     if (T.n_nodes == 0) return closest;
     int n = 1;
     stk[0] = 1u;
@@ -561,7 +639,7 @@ __device__ Hit hit_mesh_tree(const Scene64& S, int tree, const Ray& r, real t_mi
         }
         const Node64& node = S.nodes[(size_t)T.node_base + stk[(n - 1) * R64_BLOCK] - 1u];
         n -= 1;
-        if (!hit_aabb(node.box, r, t_min, t_max)) continue;
+        if (!hit_aabb_fast(node.box, r, inv, t_min, t_max)) continue;
         if (node.leaf) {
             if (active_mesh_index == 0) {
                 stk[(n++) * R64_BLOCK] = (uint32_t)node.right;
@@ -570,13 +648,13 @@ __device__ Hit hit_mesh_tree(const Scene64& S, int tree, const Ray& r, real t_mi
             } else {
                 int oi = S.tree_objects[T.obj_base + (int)stk[(active_mesh_index - 1) * R64_BLOCK] - 1];
                 const Mesh64 m = S.meshes[S.objects[oi].aux];
-                Hit lh = miss(); // src/mesh.jl:61-71
+                Lite lh = lite_miss(); // src/mesh.jl:61-71
                 real tm = t_max;
                 for (int i = node.left; i <= node.right; ++i) {
-                    Hit h = hit_mesh_triangle(S, m, i, r, t_min, tm);
-                    if (h.t < lh.t) { lh = h; tm = lh.t; }
+                    real t = hit_mesh_triangle(S, m, i, r, t_min, tm).t;
+                    if (t < lh.t) { lh.t = t; lh.bound = tm; lh.oi = oi; lh.inner = i; tm = t; }
                 }
-                if (lh.t < closest.t) { closest = lh; closest.prim = S.top_pos[oi]; }
+                if (lh.t < closest.t) closest = lh;
             }
         } else {
             stk[(n++) * R64_BLOCK] = (uint32_t)node.left;
@@ -586,18 +664,47 @@ __device__ Hit hit_mesh_tree(const Scene64& S, int tree, const Ray& r, real t_mi
     return closest;
 }
 
+// The record of the hit that is left: the winning object's test once more (see Lite).
+__device__ Hit complete_hit(const Scene64& S, const Ray& r, real t_min, const Lite& l, const Ctx& c) {
+    if (l.t == R64_INF) return miss();
+    const rtObject64& o = S.objects[l.oi];
+    Hit h;
+    if (o.kind == RT_MESH) {
+        h = hit_mesh_triangle(S, S.meshes[o.aux], l.inner, r, t_min, l.bound);
+    } else if (o.kind == RT_CONSTANT_MEDIUM) {
+        h = hit_medium(S, l.oi, r, t_min, l.bound, c);
+    } else if (o.kind == RT_BVH) {
+        h = hit_simple(S, l.inner, r, t_min, l.inner_bound);
+        h.sub = l.inner;
+    } else if (o.kind == RT_TRANSFORM && S.objects[o.child].kind == RT_BVH) { // src/transform.jl:104-116 around the tree
+        const rtTransform64& T = S.transforms[o.aux];
+        h = hit_simple(S, l.inner, to_object_frame(T, r), t_min, l.inner_bound);
+        h.sub = l.inner;
+        h.p = at(r, h.t);
+        h.n = apply_vec(T.xform, h.n);
+    } else {
+        h = hit_simple(S, l.oi, r, t_min, l.bound);
+    }
+    h.prim = S.top_pos[l.oi];
+    return h;
+}
+
 // src/scene_manager.jl:40-53: the closest over the type groups; the bound moves only when a later group's hit replaces
 // the one held
-__device__ Hit hit_scene(const Scene64& S, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk) {
-    Hit a = miss();
+__device__ Lite hit_scene_lite(const Scene64& S, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk) {
+    Lite a = lite_miss();
     real closest_t = t_max;
+    const V3 inv = reciprocal(r.d);
     for (int b = 0; b < S.n_buckets; ++b) {
-        Hit h = S.trees[b].is_mesh ? hit_mesh_tree(S, b, r, t_min, closest_t, stk) : hit_tree<false>(S, b, r, t_min, closest_t, c, stk, 0);
+        Lite h = S.trees[b].is_mesh ? hit_mesh_tree(S, b, r, inv, t_min, closest_t, stk) : hit_tree<false>(S, b, r, inv, t_min, closest_t, c, stk, 0);
         if (b == 0) { a = h; continue; }
         if (a.t <= h.t) { /* keep a */ }
         else { closest_t = h.t; a = h; }
     }
     return a;
+}
+__device__ Hit hit_scene(const Scene64& S, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk) {
+    return complete_hit(S, r, t_min, hit_scene_lite(S, r, t_min, t_max, c, stk), c);
 }
 
 // ------------------------------------------------------------------ src/perlin.jl, src/texture.jl
@@ -771,10 +878,9 @@ __device__ inline void start_path(const Frame64& F, int i, int j, int col, Path&
     P.depth = F.max_depth;
     P.c.bounce = 0;
 }
-// one iteration of the loop of trace(); true when the path has ended (P.color is its radiance)
-__device__ inline bool bounce(const Scene64& S, const Frame64& F, Path& P, uint32_t* stk) {
-    if (P.depth <= 0) return true;
-    Hit h = hit_scene(S, P.ray, 0.001, R64_INF, P.c, stk);
+// The part of one iteration of the loop of trace() that follows hit(scene, ray); true when the path has ended
+// (P.color is its radiance)
+__device__ inline bool shade(const Scene64& S, const Frame64& F, Path& P, const Hit& h) {
     if (h.t == R64_INF) {
         P.color = P.color + P.acc * v3(F.bg[0], F.bg[1], F.bg[2]);
         return true;
@@ -790,47 +896,126 @@ __device__ inline bool bounce(const Scene64& S, const Frame64& F, Path& P, uint3
     P.c.bounce += 1;
     return P.depth <= 0;
 }
+// one whole iteration (the parity hook's loop)
+__device__ inline bool bounce(const Scene64& S, const Frame64& F, Path& P, uint32_t* stk) {
+    if (P.depth <= 0) return true;
+    return shade(S, F, P, hit_scene(S, P.ray, 0.001, R64_INF, P.c, stk));
+}
 
 // ------------------------------------------------------------------ kernels
-// radiance: 3 reals per path of the batch, path = column position in the batch * pixels + pixel (pixel = j * width + i)
-__global__ __launch_bounds__(R64_BLOCK) void rt64_paths_kernel(Scene64 S, Frame64 F, unsigned long long* next_path, real* radiance) {
+// A frame is traced wavefront by wavefront over a pool of slots, a path per slot: rt64_extend_kernel finds the closest
+// hit of every slot's ray (the walk: registers for a ray and the hits in flight, nothing of the path), rt64_shade_kernel
+// completes the hit, scatters, and hands a slot whose path has ended the next unstarted path (one atomic per wave).
+// Apart they hold two to three times as many waves per SIMD as one kernel doing both, and the walk is bound by the
+// latency of its node fetches.  Slot state, plane by plane (plane p of slot s at [p * n_slots + s]): reals 0-2 origin,
+// 3-5 direction, 6 time, 7-9 acc, 10-12 color, 13-15 the hit (t, bound, inner bound); ints 0 depth left (0: wants a
+// path, -1: none left for it), 1 pixel, 2 pattern column, 3-4 the hit (object, inner), 5-6 the path's number.
+enum { PD_O = 0, PD_D = 3, PD_TIME = 6, PD_ACC = 7, PD_COLOR = 10, PD_T = 13, PD_BOUND = 14, PD_INNER_BOUND = 15, PD_PLANES = 16 };
+enum { PI_DEPTH = 0, PI_PIXEL = 1, PI_SAMPLE = 2, PI_OI = 3, PI_INNER = 4, PI_PATH_LO = 5, PI_PATH_HI = 6, PI_PLANES = 7 };
+struct Pool64 {
+    real* d;
+    int32_t* i;
+    uint32_t n_slots, pad;
+};
+
+__global__ __launch_bounds__(R64_BLOCK) __attribute__((amdgpu_waves_per_eu(R64_WAVES, R64_WAVES)))
+void rt64_extend_kernel(Scene64 S, Frame64 F, Pool64 pool) {
     __shared__ uint32_t stack[R64_STACK * R64_BLOCK];
-    uint32_t* stk = stack + threadIdx.x;
+    const uint32_t slot = blockIdx.x * R64_BLOCK + threadIdx.x;
+    if (slot >= pool.n_slots) return;
+    const size_t N = pool.n_slots;
+    const int depth = pool.i[PI_DEPTH * N + slot];
+    if (depth <= 0) return;
+    Ray r;
+    r.o = v3(pool.d[(PD_O + 0) * N + slot], pool.d[(PD_O + 1) * N + slot], pool.d[(PD_O + 2) * N + slot]);
+    r.d = v3(pool.d[(PD_D + 0) * N + slot], pool.d[(PD_D + 1) * N + slot], pool.d[(PD_D + 2) * N + slot]);
+    r.time = pool.d[PD_TIME * N + slot];
+    Ctx c;
+    c.pixel = (uint32_t)pool.i[PI_PIXEL * N + slot];
+    c.sample = (uint32_t)pool.i[PI_SAMPLE * N + slot];
+    c.seed32 = F.seed32;
+    c.bounce = (uint32_t)(F.max_depth - depth);
+    Lite l = hit_scene_lite(S, r, 0.001, R64_INF, c, stack + threadIdx.x);
+    pool.d[PD_T * N + slot] = l.t;
+    pool.d[PD_BOUND * N + slot] = l.bound;
+    pool.d[PD_INNER_BOUND * N + slot] = l.inner_bound;
+    pool.i[PI_OI * N + slot] = l.oi;
+    pool.i[PI_INNER * N + slot] = l.inner;
+}
+
+// radiance: 3 reals per path of the batch, path = column position in the batch * pixels + pixel (pixel = j * width + i).
+// live: incremented by the number of slots that leave this launch with a path (the host stops at 0).
+__global__ __launch_bounds__(R64_BLOCK) void rt64_shade_kernel(Scene64 S, Frame64 F, Pool64 pool, unsigned long long* next_path, real* radiance,
+                                                               uint32_t* live) {
+    const uint32_t slot = blockIdx.x * R64_BLOCK + threadIdx.x;
     const unsigned lane = threadIdx.x & 63u;
-    const unsigned long long pixels = (unsigned long long)F.width * (unsigned long long)F.height;
-    bool active = false, done = false;
-    unsigned long long mine = 0;
+    const size_t N = pool.n_slots;
+    const bool in_pool = slot < pool.n_slots;
+    int depth = in_pool ? pool.i[PI_DEPTH * N + slot] : -1;
     Path P;
-    for (;;) {
-        if (!active && !done) {
-            // the lanes of the wave without a path take the next ones together: one atomic
-            unsigned long long want = __ballot(1);
-            unsigned leader = (unsigned)__ffsll((long long)want) - 1u;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(next_path, (unsigned long long)__popcll(want));
-            unsigned lo = __shfl((unsigned)(base & 0xffffffffull), (int)leader);
-            unsigned hi = __shfl((unsigned)(base >> 32), (int)leader);
-            base = ((unsigned long long)hi << 32) | lo;
-            mine = base + (unsigned long long)__popcll(want & ((1ull << lane) - 1ull));
-            if (mine < F.n_paths) {
-                unsigned long long pos = mine / pixels, pixel = mine % pixels;
-                int col = F.first + (F.batch_first + (int)pos) * F.stride;
-                start_path(F, (int)(pixel % (unsigned long long)F.width), (int)(pixel / (unsigned long long)F.width), col, P);
-                active = true;
-            } else {
-                done = true;
-            }
-        }
-        if (!__any(active)) break;
-        if (active) {
-            if (bounce(S, F, P, stk)) {
-                radiance[3 * mine] = P.color.x;
-                radiance[3 * mine + 1] = P.color.y;
-                radiance[3 * mine + 2] = P.color.z;
-                active = false;
-            }
+    bool want = depth == 0;
+    if (depth > 0) {
+        P.ray.o = v3(pool.d[(PD_O + 0) * N + slot], pool.d[(PD_O + 1) * N + slot], pool.d[(PD_O + 2) * N + slot]);
+        P.ray.d = v3(pool.d[(PD_D + 0) * N + slot], pool.d[(PD_D + 1) * N + slot], pool.d[(PD_D + 2) * N + slot]);
+        P.ray.time = pool.d[PD_TIME * N + slot];
+        P.acc = v3(pool.d[(PD_ACC + 0) * N + slot], pool.d[(PD_ACC + 1) * N + slot], pool.d[(PD_ACC + 2) * N + slot]);
+        P.color = v3(pool.d[(PD_COLOR + 0) * N + slot], pool.d[(PD_COLOR + 1) * N + slot], pool.d[(PD_COLOR + 2) * N + slot]);
+        P.depth = depth;
+        P.c.pixel = (uint32_t)pool.i[PI_PIXEL * N + slot];
+        P.c.sample = (uint32_t)pool.i[PI_SAMPLE * N + slot];
+        P.c.seed32 = F.seed32;
+        P.c.bounce = (uint32_t)(F.max_depth - depth);
+        Lite l;
+        l.t = pool.d[PD_T * N + slot];
+        l.bound = pool.d[PD_BOUND * N + slot];
+        l.inner_bound = pool.d[PD_INNER_BOUND * N + slot];
+        l.oi = pool.i[PI_OI * N + slot];
+        l.inner = pool.i[PI_INNER * N + slot];
+        Hit h = complete_hit(S, P.ray, 0.001, l, P.c);
+        if (shade(S, F, P, h)) {
+            unsigned long long mine = ((unsigned long long)(uint32_t)pool.i[PI_PATH_HI * N + slot] << 32) | (uint32_t)pool.i[PI_PATH_LO * N + slot];
+            radiance[3 * mine] = P.color.x;
+            radiance[3 * mine + 1] = P.color.y;
+            radiance[3 * mine + 2] = P.color.z;
+            want = true;
         }
     }
+    bool fresh = false;
+    if (want) {
+        // the lanes of the wave without a path take the next ones together: one atomic
+        unsigned long long mask = __ballot(1);
+        unsigned leader = (unsigned)__ffsll((long long)mask) - 1u;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(next_path, (unsigned long long)__popcll(mask));
+        unsigned lo = __shfl((unsigned)(base & 0xffffffffull), (int)leader);
+        unsigned hi = __shfl((unsigned)(base >> 32), (int)leader);
+        unsigned long long mine = (((unsigned long long)hi << 32) | lo) + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+        if (mine < F.n_paths) {
+            const unsigned long long pixels = (unsigned long long)F.width * (unsigned long long)F.height;
+            unsigned long long pos = mine / pixels, pixel = mine % pixels;
+            int col = F.first + (F.batch_first + (int)pos) * F.stride;
+            start_path(F, (int)(pixel % (unsigned long long)F.width), (int)(pixel / (unsigned long long)F.width), col, P);
+            pool.i[PI_PIXEL * N + slot] = (int32_t)P.c.pixel;
+            pool.i[PI_SAMPLE * N + slot] = (int32_t)P.c.sample;
+            pool.i[PI_PATH_LO * N + slot] = (int32_t)(uint32_t)(mine & 0xffffffffull);
+            pool.i[PI_PATH_HI * N + slot] = (int32_t)(uint32_t)(mine >> 32);
+            fresh = true;
+        } else {
+            pool.i[PI_DEPTH * N + slot] = -1;
+            depth = -1;
+        }
+    }
+    const bool alive = in_pool && (fresh || (depth > 0 && !want));
+    if (alive) {
+        pool.d[(PD_O + 0) * N + slot] = P.ray.o.x; pool.d[(PD_O + 1) * N + slot] = P.ray.o.y; pool.d[(PD_O + 2) * N + slot] = P.ray.o.z;
+        pool.d[(PD_D + 0) * N + slot] = P.ray.d.x; pool.d[(PD_D + 1) * N + slot] = P.ray.d.y; pool.d[(PD_D + 2) * N + slot] = P.ray.d.z;
+        pool.d[PD_TIME * N + slot] = P.ray.time;
+        pool.d[(PD_ACC + 0) * N + slot] = P.acc.x; pool.d[(PD_ACC + 1) * N + slot] = P.acc.y; pool.d[(PD_ACC + 2) * N + slot] = P.acc.z;
+        pool.d[(PD_COLOR + 0) * N + slot] = P.color.x; pool.d[(PD_COLOR + 1) * N + slot] = P.color.y; pool.d[(PD_COLOR + 2) * N + slot] = P.color.z;
+        pool.i[PI_DEPTH * N + slot] = P.depth;
+    }
+    unsigned long long alive_mask = __ballot(alive);
+    if (lane == 0 && alive_mask) atomicAdd(live, (uint32_t)__popcll(alive_mask));
 }
 
 // accum (Julia Array{RGB{Float64}}(H, W) order) += the batch's radiances, column after column: the sample loop of draw!
@@ -896,8 +1081,11 @@ struct rtScene64 {
     real* d_radiance = nullptr; size_t radiance_cap = 0; // in reals
     real* d_accum = nullptr; size_t accum_cap = 0;
     unsigned long long* d_next = nullptr;
+    real* d_pool = nullptr; size_t pool_cap = 0;      // the slots' real planes
+    int32_t* d_pool_i = nullptr; size_t pool_i_cap = 0; // ... and int planes
+    uint32_t* d_live = nullptr;                        // R64_SYNC_EVERY counters of slots alive after a shade launch
+    uint32_t* h_live = nullptr;                        // pinned mirror
     int n_cus = 0;
-    int blocks_per_cu = 0; // resident workgroups of rt64_paths_kernel per CU
 };
 
 namespace {
@@ -928,6 +1116,7 @@ struct Staged64 {
     std::vector<Node64> nodes;
     std::vector<int32_t> tree_objects;
     std::vector<Tree64> trees;
+    std::vector<uint8_t> mat_uv;
 };
 
 // a plain object (what hit_basic takes)
@@ -1111,6 +1300,13 @@ int stage_scene64(const rtSceneDesc64& D, Staged64& H, int* stack_need) {
     if (D.n_materials) H.materials.assign(D.materials, D.materials + D.n_materials);
     if (D.n_textures) H.textures.assign(D.textures, D.textures + D.n_textures);
     if (D.n_perlins) H.perlins.assign(D.perlins, D.perlins + D.n_perlins);
+    // which textures read (u, v): image textures, and checkers over them (a checker's textures precede it)
+    std::vector<uint8_t> tex_uv((size_t)D.n_textures, 0);
+    for (int i = 0; i < D.n_textures; ++i) {
+        const rtTexture64& t = D.textures[i];
+        tex_uv[(size_t)i] = t.kind == RT_TEX_IMAGE || (t.kind == RT_TEX_CHECKER && (tex_uv[(size_t)t.a] || tex_uv[(size_t)t.b]));
+    }
+    for (int i = 0; i < D.n_materials; ++i) H.mat_uv.push_back(tex_uv[(size_t)D.materials[i].texture]);
     return RT_OK;
 }
 
@@ -1133,11 +1329,15 @@ int check_frame64(const char* who, rtScene64* s, const rtCamera64* cam, const re
 // the radiance buffer holds this many column batches' worth of paths at most (bytes)
 const size_t R64_RADIANCE_BUDGET = (size_t)8 << 30;
 
+// slots of the pool (156 bytes each); bounce launches between two looks at the live counter
+const uint32_t R64_MAX_SLOTS = 2u << 20;
+const int R64_SYNC_EVERY = 8;
+
 int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n, int first, int stride, const real* bg, int width, int height,
                  int max_depth, uint64_t seed, real* d_accum, hipStream_t stream) {
     size_t pixels = (size_t)width * (size_t)height;
     int count = first < n ? (n - first + stride - 1) / stride : 0;
-    if (count == 0) {
+    if (count == 0 || max_depth <= 0) { // no column of this shard, or trace() returns zero(Vec3) at once
         HIP_TRY64(hipMemsetAsync(d_accum, 0, 3 * pixels * sizeof(real), stream));
         return RT_OK;
     }
@@ -1151,6 +1351,11 @@ int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n
     st = grow64(&s->d_radiance, &s->radiance_cap, (size_t)cols_per_batch * 3 * pixels);
     if (st != RT_OK) return st;
     if (!s->d_next) HIP_TRY64(hipMalloc((void**)&s->d_next, sizeof(unsigned long long)));
+    if (!s->d_live) HIP_TRY64(hipMalloc((void**)&s->d_live, R64_SYNC_EVERY * sizeof(uint32_t)));
+    if (!s->h_live) HIP_TRY64(hipHostMalloc((void**)&s->h_live, R64_SYNC_EVERY * sizeof(uint32_t)));
+    uint32_t max_slots = R64_MAX_SLOTS;
+    if (const char* e = getenv("RT_AMD_F64_SLOTS")) // for tests and tuning
+        if (atoi(e) > 0) max_slots = (uint32_t)atoi(e);
     Frame64 F;
     F.cam = *cam;
     F.pattern = s->d_pattern;
@@ -1162,11 +1367,35 @@ int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n
         int cols = std::min(cols_per_batch, count - b0);
         F.batch_first = b0; F.batch_cols = cols;
         F.n_paths = (unsigned long long)cols * (unsigned long long)pixels;
+        Pool64 pool;
+        pool.n_slots = (uint32_t)std::min<unsigned long long>((F.n_paths + R64_BLOCK - 1) / R64_BLOCK * R64_BLOCK, max_slots);
+        pool.pad = 0;
+        st = grow64(&s->d_pool, &s->pool_cap, (size_t)PD_PLANES * pool.n_slots);
+        if (st == RT_OK) st = grow64(&s->d_pool_i, &s->pool_i_cap, (size_t)PI_PLANES * pool.n_slots);
+        if (st != RT_OK) return st;
+        pool.d = s->d_pool;
+        pool.i = s->d_pool_i;
+        const dim3 grid((pool.n_slots + R64_BLOCK - 1) / R64_BLOCK), block(R64_BLOCK);
         HIP_TRY64(hipMemsetAsync(s->d_next, 0, sizeof(unsigned long long), stream));
-        // persistent waves: enough workgroups to fill every CU, no more than the paths need
-        unsigned long long wanted = (F.n_paths + R64_BLOCK - 1) / R64_BLOCK;
-        unsigned blocks = (unsigned)std::min<unsigned long long>(wanted, (unsigned long long)s->n_cus * (unsigned long long)s->blocks_per_cu);
-        hipLaunchKernelGGL(rt64_paths_kernel, dim3(blocks), dim3(R64_BLOCK), 0, stream, s->dev, F, s->d_next, s->d_radiance);
+        HIP_TRY64(hipMemsetAsync(pool.i, 0, (size_t)pool.n_slots * sizeof(int32_t), stream)); // depth plane: every slot wants a path
+        HIP_TRY64(hipMemsetAsync(s->d_live, 0, R64_SYNC_EVERY * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(rt64_shade_kernel, grid, block, 0, stream, s->dev, F, pool, s->d_next, s->d_radiance, s->d_live); // the first paths
+        // every path ends within max_depth bounces of its start, and a launch that starts none ends the frame soon after:
+        // the loop is bounded by the paths there are
+        const unsigned long long most = (F.n_paths / pool.n_slots + 2ull) * (unsigned long long)(max_depth + 1) + 8ull;
+        bool done = false;
+        for (unsigned long long it = 0; !done; it += R64_SYNC_EVERY) {
+            if (it > most) return rt_fail(RT_EHIP, "rt_render_f64: the frame did not end within %llu bounces", most);
+            HIP_TRY64(hipMemsetAsync(s->d_live, 0, R64_SYNC_EVERY * sizeof(uint32_t), stream));
+            for (int k = 0; k < R64_SYNC_EVERY; ++k) {
+                hipLaunchKernelGGL(rt64_extend_kernel, grid, block, 0, stream, s->dev, F, pool);
+                hipLaunchKernelGGL(rt64_shade_kernel, grid, block, 0, stream, s->dev, F, pool, s->d_next, s->d_radiance, s->d_live + k);
+            }
+            HIP_TRY64(hipGetLastError());
+            HIP_TRY64(hipMemcpyAsync(s->h_live, s->d_live, R64_SYNC_EVERY * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY64(hipStreamSynchronize(stream));
+            done = s->h_live[R64_SYNC_EVERY - 1] == 0;
+        }
         hipLaunchKernelGGL(rt64_sum_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, (const real*)s->d_radiance, cols, width,
                            height, b0 == 0 ? 1 : 0, d_accum);
         HIP_TRY64(hipGetLastError());
@@ -1194,8 +1423,6 @@ extern "C" int rt_scene_create_f64(const rtSceneDesc64* desc, int device, rtScen
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->n_cus = prop.multiProcessorCount;
     if (s->n_cus <= 0) s->n_cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&s->blocks_per_cu, rt64_paths_kernel, R64_BLOCK, 0) != hipSuccess || s->blocks_per_cu <= 0)
-        s->blocks_per_cu = 4;
     Scene64& d = s->dev;
 #define UP64(field, vec)                                              \
     do {                                                              \
@@ -1206,9 +1433,12 @@ extern "C" int rt_scene_create_f64(const rtSceneDesc64* desc, int device, rtScen
     UP64(textures, H.textures); UP64(images, H.images); UP64(texels, H.texels); UP64(perlins, H.perlins);
     UP64(meshes, H.meshes); UP64(vertices, H.vertices); UP64(indices, H.indices); UP64(tri_ids, H.tri_ids);
     UP64(mesh_materials, H.mesh_materials); UP64(nodes, H.nodes); UP64(tree_objects, H.tree_objects); UP64(trees, H.trees);
+    UP64(mat_uv, H.mat_uv);
 #undef UP64
     d.n_buckets = desc->n_buckets;
     d.n_groups = desc->n_groups;
+    d.all_uv = 0;
+    d.pad = 0;
     *out = s;
     return RT_OK;
 }
@@ -1222,6 +1452,10 @@ extern "C" int rt_scene_destroy_f64(rtScene64* s) {
     if (s->d_radiance) (void)hipFree(s->d_radiance);
     if (s->d_accum) (void)hipFree(s->d_accum);
     if (s->d_next) (void)hipFree(s->d_next);
+    if (s->d_pool) (void)hipFree(s->d_pool);
+    if (s->d_pool_i) (void)hipFree(s->d_pool_i);
+    if (s->d_live) (void)hipFree(s->d_live);
+    if (s->h_live) (void)hipHostFree(s->h_live);
     delete s;
     return RT_OK;
 }
@@ -1295,7 +1529,9 @@ extern "C" int rt_trace_rays_f64(rtScene64* s, const double* rays, int n, double
         HIP_TRY64(hipMalloc((void**)&d_sub, (size_t)n * sizeof(int32_t)));
         HIP_TRY64(hipMalloc((void**)&d_front, (size_t)n));
         HIP_TRY64(hipMemcpy(d_rays, rays, (size_t)7 * n * sizeof(real), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(rt64_trace_rays_kernel, dim3((unsigned)((n + R64_BLOCK - 1) / R64_BLOCK)), dim3(R64_BLOCK), 0, nullptr, s->dev,
+        Scene64 with_uv = s->dev;
+        with_uv.all_uv = 1;
+        hipLaunchKernelGGL(rt64_trace_rays_kernel, dim3((unsigned)((n + R64_BLOCK - 1) / R64_BLOCK)), dim3(R64_BLOCK), 0, nullptr, with_uv,
                            (const real*)d_rays, n, t_min, t_max, fold_seed(seed), d_prim, d_sub, d_t, d_n, d_uv, d_front);
         HIP_TRY64(hipGetLastError());
         HIP_TRY64(hipDeviceSynchronize());
