@@ -336,8 +336,8 @@ int rt_perlin_generate(uint32_t seed, uint64_t* counter, int32_t vector, rtPerli
  * reference's own box test in double, so results equal the CPU path's for Float64 bit for bit (random numbers: 53
  * bits from two words of the same counter-based generator).  Image buffers are double: the memory order of a Julia
  * Array{RGB{Float64},2}(H, W).  Unsupported nestings are the Float32 path's (RT_EUNSUPPORTED); in addition the trees
- * may need at most 48 stack entries per walk (a tree of meshes: its two levels together), which holds for any tree the
- * reference's median split builds over fewer than 2^40 objects. */
+ * may need at most 40 stack entries per walk (a tree of meshes: its two levels together), which holds for any tree the
+ * reference's median split builds over fewer than 2^30 objects. */
 typedef struct rtObject64 { int32_t kind, material, child, aux; double p[12]; } rtObject64;     /* as rtObject */
 typedef struct rtTransform64 { double xform[12], inv_xform[12], bbox[6]; } rtTransform64;       /* as rtTransform */
 typedef struct rtMaterial64 { int32_t type, texture; double fuzz, eta; } rtMaterial64;          /* as rtMaterial */

@@ -32,10 +32,7 @@ namespace {
 typedef double real;
 #define R64_INF (__builtin_inf())
 #define R64_BLOCK 128
-#define R64_STACK 48
-#ifndef R64_WAVES
-#define R64_WAVES 3 // waves per SIMD the path kernel is compiled for (registers per lane: 512 / R64_WAVES)
-#endif
+#define R64_STACK 40 // stack entries per lane: 20 KB of LDS per workgroup, eight workgroups (four waves per SIMD) per CU
 
 #define HIP_TRY64(expr)                                                                                   \
     do {                                                                                                  \
@@ -554,7 +551,9 @@ __device__ inline Lite lite_miss() {
 }
 
 // stk: the calling lane's column of the stack in LDS (entry e at stk[e * R64_BLOCK]); sp0: entries already in use
-template <bool NESTED>
+// GROUPS: the scene has nested trees (BVHTree objects); a scene without them is walked by code that does not hold the
+// registers a second, inner walk needs (128 instead of 168: four waves per SIMD instead of three)
+template <bool NESTED, bool GROUPS>
 __device__ Lite hit_tree(const Scene64& S, int tree, const Ray& r, const V3& inv, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp0);
 
 // the ray in the frame of a Transform (src/transform.jl:105-107)
@@ -567,20 +566,20 @@ __device__ inline Ray to_object_frame(const rtTransform64& T, const Ray& r) {
 }
 
 // distance of the hit of object oi (Inf: none); for a nested tree also which object inside it and with what bound
-template <bool NESTED>
+template <bool NESTED, bool GROUPS>
 __device__ inline real hit_object_t(const Scene64& S, int oi, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp,
                                     int32_t& inner, real& inner_bound) {
     const rtObject64& o = S.objects[oi];
     if (!NESTED) {
         if (o.kind == RT_CONSTANT_MEDIUM) return hit_medium(S, oi, r, t_min, t_max, c).t;
         const bool wrapped = o.kind == RT_TRANSFORM && S.objects[o.child].kind == RT_BVH;
-        if (o.kind == RT_BVH || wrapped) {
+        if (GROUPS && (o.kind == RT_BVH || wrapped)) {
             Lite l;
             if (wrapped) {
                 Ray rr = to_object_frame(S.transforms[o.aux], r);
-                l = hit_tree<true>(S, S.n_buckets + S.objects[o.child].aux, rr, reciprocal(rr.d), t_min, t_max, c, stk, sp);
+                l = hit_tree<true, GROUPS>(S, S.n_buckets + S.objects[o.child].aux, rr, reciprocal(rr.d), t_min, t_max, c, stk, sp);
             } else {
-                l = hit_tree<true>(S, S.n_buckets + o.aux, r, reciprocal(r.d), t_min, t_max, c, stk, sp);
+                l = hit_tree<true, GROUPS>(S, S.n_buckets + o.aux, r, reciprocal(r.d), t_min, t_max, c, stk, sp);
             }
             inner = l.oi;
             inner_bound = l.bound;
@@ -590,7 +589,7 @@ __device__ inline real hit_object_t(const Scene64& S, int oi, const Ray& r, real
     return hit_simple(S, oi, r, t_min, t_max).t;
 }
 
-template <bool NESTED>
+template <bool NESTED, bool GROUPS>
 __device__ Lite hit_tree(const Scene64& S, int tree, const Ray& r, const V3& inv, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp0) { // src/BVH.jl:22-53
     const Tree64 T = S.trees[tree];
     Lite closest = lite_miss();
@@ -608,7 +607,7 @@ __device__ Lite hit_tree(const Scene64& S, int tree, const Ray& r, const V3& inv
                 int oi = S.tree_objects[T.obj_base + i - 1];
                 int32_t inner = -1;
                 real inner_bound = R64_INF;
-                real t = hit_object_t<NESTED>(S, oi, r, t_min, tm, c, stk, n, inner, inner_bound);
+                real t = hit_object_t<NESTED, GROUPS>(S, oi, r, t_min, tm, c, stk, n, inner, inner_bound);
                 if (t < lh.t) {
                     lh.t = t; lh.bound = tm; lh.oi = oi; lh.inner = inner; lh.inner_bound = inner_bound;
                     tm = t;
@@ -691,12 +690,13 @@ __device__ Hit complete_hit(const Scene64& S, const Ray& r, real t_min, const Li
 
 // src/scene_manager.jl:40-53: the closest over the type groups; the bound moves only when a later group's hit replaces
 // the one held
+template <bool GROUPS>
 __device__ Lite hit_scene_lite(const Scene64& S, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk) {
     Lite a = lite_miss();
     real closest_t = t_max;
     const V3 inv = reciprocal(r.d);
     for (int b = 0; b < S.n_buckets; ++b) {
-        Lite h = S.trees[b].is_mesh ? hit_mesh_tree(S, b, r, inv, t_min, closest_t, stk) : hit_tree<false>(S, b, r, inv, t_min, closest_t, c, stk, 0);
+        Lite h = S.trees[b].is_mesh ? hit_mesh_tree(S, b, r, inv, t_min, closest_t, stk) : hit_tree<false, GROUPS>(S, b, r, inv, t_min, closest_t, c, stk, 0);
         if (b == 0) { a = h; continue; }
         if (a.t <= h.t) { /* keep a */ }
         else { closest_t = h.t; a = h; }
@@ -704,7 +704,7 @@ __device__ Lite hit_scene_lite(const Scene64& S, const Ray& r, real t_min, real 
     return a;
 }
 __device__ Hit hit_scene(const Scene64& S, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk) {
-    return complete_hit(S, r, t_min, hit_scene_lite(S, r, t_min, t_max, c, stk), c);
+    return complete_hit(S, r, t_min, hit_scene_lite<true>(S, r, t_min, t_max, c, stk), c);
 }
 
 // ------------------------------------------------------------------ src/perlin.jl, src/texture.jl
@@ -918,7 +918,8 @@ struct Pool64 {
     uint32_t n_slots, pad;
 };
 
-__global__ __launch_bounds__(R64_BLOCK) __attribute__((amdgpu_waves_per_eu(R64_WAVES, R64_WAVES)))
+template <bool GROUPS>
+__global__ __launch_bounds__(R64_BLOCK) __attribute__((amdgpu_waves_per_eu(GROUPS ? 3 : 4, GROUPS ? 3 : 4)))
 void rt64_extend_kernel(Scene64 S, Frame64 F, Pool64 pool) {
     __shared__ uint32_t stack[R64_STACK * R64_BLOCK];
     const uint32_t slot = blockIdx.x * R64_BLOCK + threadIdx.x;
@@ -935,7 +936,7 @@ void rt64_extend_kernel(Scene64 S, Frame64 F, Pool64 pool) {
     c.sample = (uint32_t)pool.i[PI_SAMPLE * N + slot];
     c.seed32 = F.seed32;
     c.bounce = (uint32_t)(F.max_depth - depth);
-    Lite l = hit_scene_lite(S, r, 0.001, R64_INF, c, stack + threadIdx.x);
+    Lite l = hit_scene_lite<GROUPS>(S, r, 0.001, R64_INF, c, stack + threadIdx.x);
     pool.d[PD_T * N + slot] = l.t;
     pool.d[PD_BOUND * N + slot] = l.bound;
     pool.d[PD_INNER_BOUND * N + slot] = l.inner_bound;
@@ -1388,7 +1389,8 @@ int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n
             if (it > most) return rt_fail(RT_EHIP, "rt_render_f64: the frame did not end within %llu bounces", most);
             HIP_TRY64(hipMemsetAsync(s->d_live, 0, R64_SYNC_EVERY * sizeof(uint32_t), stream));
             for (int k = 0; k < R64_SYNC_EVERY; ++k) {
-                hipLaunchKernelGGL(rt64_extend_kernel, grid, block, 0, stream, s->dev, F, pool);
+                if (s->dev.n_groups > 0) hipLaunchKernelGGL(rt64_extend_kernel<true>, grid, block, 0, stream, s->dev, F, pool);
+                else hipLaunchKernelGGL(rt64_extend_kernel<false>, grid, block, 0, stream, s->dev, F, pool);
                 hipLaunchKernelGGL(rt64_shade_kernel, grid, block, 0, stream, s->dev, F, pool, s->d_next, s->d_radiance, s->d_live + k);
             }
             HIP_TRY64(hipGetLastError());

@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import raytracing_amd as rt
 
 cols = int(sys.argv[1]) if len(sys.argv) > 1 else 16
