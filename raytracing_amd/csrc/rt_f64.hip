@@ -43,10 +43,21 @@ typedef double real;
     } while (0)
 
 // ------------------------------------------------------------------ device tables
-struct Node64 { // src/BVH.jl:5-10
+struct __align__(64) Node64 { // src/BVH.jl:5-10 (one 64-byte line: four 16-byte loads)
     real box[6];
     int32_t left, right; // 1-based node ids / object positions, as the reference stores them
-    int32_t leaf, pad;
+    int32_t leaf, first; // first: the object at position `left` of a leaf of a tree over objects
+};
+// What a walk needs of one object, in one record: a plain object as it is, a Transform around a plain object as that
+// object with the matrix that takes the ray to it.  The walk reaches a leaf's test after two dependent fetches (node,
+// this record) instead of four (node, object list, object, transform and wrapped object).
+struct Leaf64 {
+    int32_t kind;     // the plain object's kind; for everything else (medium, tree, mesh) the object's own kind
+    int32_t material;
+    int32_t xf;       // transform index, -1: none
+    int32_t pad;
+    real p[12];
+    real inv[12];     // src/transform.jl:65: inv_xform, 3x4 column-major
 };
 struct Tree64 {
     int32_t node_base, n_nodes, obj_base, n_objects, is_mesh, pad0, pad1, pad2;
@@ -60,6 +71,7 @@ struct Image64 {
 };
 struct Scene64 {
     const rtObject64* objects;
+    const Leaf64* fused;       // per object
     const int32_t* top_pos;
     const rtTransform64* transforms;
     const rtMaterial64* materials;
@@ -417,9 +429,9 @@ __device__ Hit hit_box(const real* p, int material, const Ray& r, real t_min, re
     return closest;
 }
 // Sphere, MovingSphere, the three rectangles, Box
-__device__ Hit hit_basic(const Scene64& S, const rtObject64& o, const Ray& r, real t_min, real t_max) {
-    const real* p = o.p;
-    const bool want_uv = S.all_uv || S.mat_uv[o.material];
+__device__ Hit hit_basic(const Scene64& S, int kind, int material, const real* p, const Ray& r, real t_min, real t_max) {
+    const bool want_uv = S.all_uv || S.mat_uv[material];
+    struct { int kind, material; } o = {kind, material};
     switch (o.kind) {
         case RT_SPHERE: return hit_sphere(v3(p[0], p[1], p[2]), p[3], o.material, r, t_min, t_max, want_uv);
         case RT_MOVING_SPHERE: { // src/sphere.jl:24-26
@@ -445,13 +457,14 @@ __device__ inline V3 apply_vec(const real* T, V3 v) {
 // a basic object, or one inside a Transform (src/transform.jl:104-116)
 __device__ Hit hit_simple(const Scene64& S, int oi, const Ray& r, real t_min, real t_max) {
     const rtObject64& o = S.objects[oi];
-    if (o.kind != RT_TRANSFORM) return hit_basic(S, o, r, t_min, t_max);
+    if (o.kind != RT_TRANSFORM) return hit_basic(S, o.kind, o.material, o.p, r, t_min, t_max);
     const rtTransform64& T = S.transforms[o.aux];
     Ray rr;
     rr.o = apply_point(T.inv_xform, r.o);
     rr.d = apply_vec(T.inv_xform, r.d);
     rr.time = r.time;
-    Hit h = hit_basic(S, S.objects[o.child], rr, t_min, t_max);
+    const rtObject64& ch = S.objects[o.child];
+    Hit h = hit_basic(S, ch.kind, ch.material, ch.p, rr, t_min, t_max);
     if (h.t == R64_INF) return h;
     h.p = at(r, h.t);
     h.n = apply_vec(T.xform, h.n);
@@ -569,6 +582,15 @@ __device__ inline Ray to_object_frame(const rtTransform64& T, const Ray& r) {
 template <bool NESTED, bool GROUPS>
 __device__ inline real hit_object_t(const Scene64& S, int oi, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp,
                                     int32_t& inner, real& inner_bound) {
+    const Leaf64& L = S.fused[oi];
+    if (L.kind >= RT_SPHERE && L.kind <= RT_BOX) { // a plain object, possibly inside a Transform: the distance carries over
+        if (L.xf < 0) return hit_basic(S, L.kind, L.material, L.p, r, t_min, t_max).t;
+        Ray rr;
+        rr.o = apply_point(L.inv, r.o);
+        rr.d = apply_vec(L.inv, r.d);
+        rr.time = r.time;
+        return hit_basic(S, L.kind, L.material, L.p, rr, t_min, t_max).t;
+    }
     const rtObject64& o = S.objects[oi];
     if (!NESTED) {
         if (o.kind == RT_CONSTANT_MEDIUM) return hit_medium(S, oi, r, t_min, t_max, c).t;
@@ -604,7 +626,7 @@ __device__ Lite hit_tree(const Scene64& S, int tree, const Ray& r, const V3& inv
             Lite lh = lite_miss();
             real tm = t_max;
             for (int i = node.left; i <= node.right; ++i) {
-                int oi = S.tree_objects[T.obj_base + i - 1];
+                int oi = i == node.left ? node.first : S.tree_objects[T.obj_base + i - 1];
                 int32_t inner = -1;
                 real inner_bound = R64_INF;
                 real t = hit_object_t<NESTED, GROUPS>(S, oi, r, t_min, tm, c, stk, n, inner, inner_bound);
@@ -1104,6 +1126,7 @@ int upload64(rtScene64* s, const std::vector<T>& v, const T** out) {
 
 struct Staged64 {
     std::vector<rtObject64> objects;
+    std::vector<Leaf64> fused;
     std::vector<int32_t> top_pos;
     std::vector<rtTransform64> transforms;
     std::vector<rtMaterial64> materials;
@@ -1284,7 +1307,8 @@ int stage_scene64(const rtSceneDesc64& D, Staged64& H, int* stack_need) {
             Node64 n;
             memcpy(n.box, T.node_bounds + 6 * (size_t)i, sizeof(n.box));
             n.left = T.node_left[i]; n.right = T.node_right[i];
-            n.leaf = T.node_leaf[i] == 1 ? 1 : 0; n.pad = 0;
+            n.leaf = T.node_leaf[i] == 1 ? 1 : 0;
+            n.first = (n.leaf && T.kind == 0 && n.left >= 1 && n.left <= T.n_objects) ? T.objects[n.left - 1] : 0;
             H.nodes.push_back(n);
         }
         H.tree_objects.insert(H.tree_objects.end(), T.objects, T.objects + T.n_objects);
@@ -1292,6 +1316,20 @@ int stage_scene64(const rtSceneDesc64& D, Staged64& H, int* stack_need) {
     }
     *stack_need = need_main + need_nested;
     H.objects.assign(D.objects, D.objects + D.n_objects);
+    for (int i = 0; i < D.n_objects; ++i) {
+        const rtObject64& o = D.objects[i];
+        Leaf64 L;
+        memset(&L, 0, sizeof(L));
+        L.kind = o.kind; L.material = o.material; L.xf = -1;
+        memcpy(L.p, o.p, sizeof(L.p));
+        if (o.kind == RT_TRANSFORM && is_basic(D.objects[o.child].kind)) {
+            const rtObject64& ch = D.objects[o.child];
+            L.kind = ch.kind; L.material = ch.material; L.xf = o.aux;
+            memcpy(L.p, ch.p, sizeof(L.p));
+            memcpy(L.inv, D.transforms[o.aux].inv_xform, sizeof(L.inv));
+        }
+        H.fused.push_back(L);
+    }
     H.top_pos.assign((size_t)D.n_objects, -1);
     for (int i = 0; i < D.n_top; ++i) {
         if (D.top[i] < 0 || D.top[i] >= D.n_objects) return fail(RT_EINVAL, "top-level object index out of range");
@@ -1369,7 +1407,11 @@ int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n
         F.batch_first = b0; F.batch_cols = cols;
         F.n_paths = (unsigned long long)cols * (unsigned long long)pixels;
         Pool64 pool;
-        pool.n_slots = (uint32_t)std::min<unsigned long long>((F.n_paths + R64_BLOCK - 1) / R64_BLOCK * R64_BLOCK, max_slots);
+        // a pool an eighth of the batch (small frames: the launches at the end of a batch, when few slots still hold a
+        // path, cost less), between 256 Ki and max_slots
+        unsigned long long want_slots = std::max<unsigned long long>(F.n_paths / 8ull, 256ull << 10);
+        want_slots = std::min<unsigned long long>(want_slots, F.n_paths);
+        pool.n_slots = (uint32_t)std::min<unsigned long long>((want_slots + R64_BLOCK - 1) / R64_BLOCK * R64_BLOCK, max_slots);
         pool.pad = 0;
         st = grow64(&s->d_pool, &s->pool_cap, (size_t)PD_PLANES * pool.n_slots);
         if (st == RT_OK) st = grow64(&s->d_pool_i, &s->pool_i_cap, (size_t)PI_PLANES * pool.n_slots);
@@ -1431,7 +1473,7 @@ extern "C" int rt_scene_create_f64(const rtSceneDesc64* desc, int device, rtScen
         st = upload64(s, vec, &d.field);                              \
         if (st != RT_OK) { rt_scene_destroy_f64(s); return st; }      \
     } while (0)
-    UP64(objects, H.objects); UP64(top_pos, H.top_pos); UP64(transforms, H.transforms); UP64(materials, H.materials);
+    UP64(objects, H.objects); UP64(fused, H.fused); UP64(top_pos, H.top_pos); UP64(transforms, H.transforms); UP64(materials, H.materials);
     UP64(textures, H.textures); UP64(images, H.images); UP64(texels, H.texels); UP64(perlins, H.perlins);
     UP64(meshes, H.meshes); UP64(vertices, H.vertices); UP64(indices, H.indices); UP64(tri_ids, H.tri_ids);
     UP64(mesh_materials, H.mesh_materials); UP64(nodes, H.nodes); UP64(tree_objects, H.tree_objects); UP64(trees, H.trees);
