@@ -202,6 +202,24 @@ def main():
                 other["%s %d spp" % (key, spp)] = {"Mpaths_per_s": paths / best / 1e6, "s_per_frame": best, "paths": paths,
                                                   "size": "%dx%d" % (k2["width"], k2["height"])}
                 sc2.close()
+            # the Float64 mode (render(Float64, ...)): the same scene with double tables through rt_*_f64, a tenth of the
+            # columns (it walks the reference's own trees in double: about a ninth of the Float32 path's rate)
+            f64_cols = max(1, n // 10)
+            w3, k3 = rt.get_scene(args.scene, spp=f64_cols, F=np.float64)
+            sc3 = rt.DeviceScene(w3, device=local_rank, F=np.float64)
+            acc3 = torch.zeros(3 * W * H, dtype=torch.float64, device=dev)
+            best = None
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                sc3.accumulate(k3["camera"], k3["pattern"], k3["background"], W, H, acc3.data_ptr(), stream=stream)
+                sc3.finalize(acc3.data_ptr(), f64_cols, W, H, acc3.data_ptr(), stream=stream)
+                torch.cuda.synchronize()
+                best = time.perf_counter() - t1
+            other["%s %d spp float64" % (args.scene, f64_cols)] = {
+                "Mpaths_per_s": W * H * f64_cols / best / 1e6, "s_per_frame": best, "paths": W * H * f64_cols,
+                "size": "%dx%d" % (W, H), "dtype": "f64"}
+            sc3.close()
             line["other_configs"] = other
         print(json.dumps(line), flush=True)
     scene.close()

@@ -136,7 +136,7 @@ class AABB:
         self.max = Vec3(mx)
 
     def as6(self):
-        return np.concatenate([self.min, self.max]).astype(F)
+        return np.concatenate([self.min, self.max])  # in the element type the box was made in
 
 
 class Hittable:

@@ -105,8 +105,10 @@ class OracleScene:
         self.rec = rec = ffi.records(F)
         self.F = rec.np_type
         self.lib = lib(self.F)
-        fl = Flattener(rec)
-        top = np.array([fl.obj(o, False) for o in world], dtype=np.int32)
+        from raytracing_amd import hittables as H
+        with H.element_type(self.F):
+            fl = Flattener(rec)
+            top = np.array([fl.obj(o, False) for o in world], dtype=np.int32)
         w = (refWorld if rec is ffi.R32 else refWorld64)()
         fl.common_tables(w)
         w.n_top, w.top = len(top), ffi.iptr(top)
