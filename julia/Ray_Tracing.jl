@@ -4,7 +4,8 @@
 # includes (cuBVH.jl, shapes.jl, scene_manager.jl, cuscene_manager.jl, camera.jl, :3-9); `using CUDA` goes away
 # (Project.toml: CUDA and Adapt out, Libdl in).  julia/apply_overlay.py makes those edits to a checkout of the reference.
 #
-# The device path works in Float32 (the reference's default, main.jl:46,83,96).
+# The device path works in Float32 (the reference's default, main.jl:46,83,96) and in Float64 (render(Float64, ...),
+# main.jl:21: the rt_*_f64 entry points, on one GPU).
 
 "Image on the GPU side of render(): what `CUDA.zeros(RGB{F}, height, width)` was (main.jl:35).  The pixels live in host
 memory the library writes into; the type only selects the method of draw!."
@@ -53,5 +54,33 @@ function draw!(img::DeviceImage{Float32}, world::SceneManager, camera::Camera{Fl
     return img
 end
 
+"""
+    draw!(img::DeviceImage{Float64}, world::SceneManager, camera; background, pattern, seed)
+
+The same for `render(Float64, ...; gpu = true)`: the trees of `build_bvh(world)` go to the library as they are, in
+double, and rt_render_f64 walks them as the CPU path does (src/BVH.jl:22-53); one GPU.
+"""
+function draw!(img::DeviceImage{Float64}, world::SceneManager, camera::Camera{Float64};
+               background::Vec3{Float64} = zero(Vec3{Float64}), pattern::Array{Float64,2} = Float64.(MSAA_S16),
+               seed::Integer = 0x5EED, devices::Union{Nothing,Vector{<:Integer}} = nothing, max_depth::Integer = 50)
+    height, width = size(img)
+    bvh = build_bvh(world)
+    scene = CuSceneManager(bvh; devices = devices)      # (a Float64 scene with `devices` is an error there)
+    bg = Float64[background.x, background.y, background.z]
+    cam = Ref(camera)                                   # Camera{Float64} has the layout of rtCamera64
+    pixels = img.pixels
+    try
+        GC.@preserve pixels pattern bg begin
+            check(ccall((:rt_render_f64, librt), Cint,
+                        (Ptr{Cvoid}, Ref{Camera{Float64}}, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Cint, Cint, UInt64, UInt32, Ptr{Float64}, Ptr{Cvoid}),
+                        scene.handle, cam, pattern, size(pattern, 2), bg, width, height, max_depth, UInt64(seed), UInt32(0),
+                        Ptr{Float64}(pointer(pixels)), C_NULL))
+        end
+    finally
+        close(scene)
+    end
+    return img
+end
+
 draw!(img::DeviceImage{F}, world::SceneManager, camera::Camera{F}; kwargs...) where F =
-    error("librt_amd: the GPU path renders in Float32; render(Float32, ...) or gpu = false")
+    error("librt_amd: the GPU path renders in Float32 or Float64, not $F")

@@ -6,10 +6,10 @@ include("BVH.jl")          # the reference's own file (src/BVH.jl): BVHNode, BVH
 include("librt_amd.jl")
 
 # What the library needs of one BVHTree, kept alive together (the RtBvh record holds raw pointers into these arrays).
-struct FlatBvh
+struct FlatBvh{F}
     kind::Int32                 # 0: generic tree (src/BVH.jl), 1: tree over meshes (src/mesh.jl:250-305)
     objects::Vector{Int32}      # 0-based indices into the object table, in tree order (tree.objects after the build)
-    bounds::Vector{Float32}     # 6 per node slot: min(3), max(3)
+    bounds::Vector{F}           # 6 per node slot: min(3), max(3), in the tree's element type (BVHNode{F}, src/BVH.jl:5-10)
     left::Vector{Int32}
     right::Vector{Int32}
     leaf::Vector{UInt8}         # 0 interior, 1 leaf, 255 slot not reached from node 1
@@ -20,7 +20,7 @@ end
 function flat_bvh(tree::BVHTree{F,T}, object_index::Function) where {F,T}
     n = length(tree.nodes)
     kind = T <: Mesh ? Int32(1) : Int32(0)      # (Mesh: src/mesh.jl:5-9, defined by the time a tree is flattened)
-    flat = FlatBvh(kind, Int32[object_index(o) for o in tree.objects], zeros(Float32, 6n), zeros(Int32, n), zeros(Int32, n),
+    flat = FlatBvh{F}(kind, Int32[object_index(o) for o in tree.objects], zeros(F, 6n), zeros(Int32, n), zeros(Int32, n),
                    fill(0xff, n))
     n == 0 && return flat
     stack = Tuple{Int,Bool}[(1, kind == 1)]     # (node id, the node belongs to the level of the meshes)
@@ -28,7 +28,7 @@ function flat_bvh(tree::BVHTree{F,T}, object_index::Function) where {F,T}
         id, mesh_level = pop!(stack)
         node = tree.nodes[id]
         b = node.box
-        flat.bounds[6id-5:6id] .= (Float32(b.min.x), Float32(b.min.y), Float32(b.min.z), Float32(b.max.x), Float32(b.max.y), Float32(b.max.z))
+        flat.bounds[6id-5:6id] .= (F(b.min.x), F(b.min.y), F(b.min.z), F(b.max.x), F(b.max.y), F(b.max.z))
         flat.left[id] = Int32(node.left)
         flat.right[id] = Int32(node.right)
         flat.leaf[id] = node.is_leaf ? 0x01 : 0x00
@@ -43,5 +43,6 @@ function flat_bvh(tree::BVHTree{F,T}, object_index::Function) where {F,T}
     return flat
 end
 
-rt_bvh(flat::FlatBvh) = RtBvh(flat.kind, Int32(length(flat.objects)), pointer(flat.objects), Int32(length(flat.leaf)), Int32(0),
-                              pointer(flat.bounds), pointer(flat.left), pointer(flat.right), pointer(flat.leaf))
+rt_bvh(flat::FlatBvh{F}) where F = records(F).bvh(flat.kind, Int32(length(flat.objects)), pointer(flat.objects), Int32(length(flat.leaf)), Int32(0),
+                                                  pointer(flat.bounds), pointer(flat.left), pointer(flat.right), pointer(flat.leaf))
+element_type(::BVHTree{F,T}) where {F,T} = F

@@ -125,6 +125,113 @@ struct RtCamera
     t1::Float32
 end
 
+# ---- F = Float64 (render(Float64, ...), main.jl:21,46): the same records with double fields (rtObject64 ... rtCamera64 of
+# include/rt_amd.h), taken by the rt_*_f64 entry points
+
+struct RtObject64
+    kind::Int32
+    material::Int32
+    child::Int32
+    aux::Int32
+    p::NTuple{12,Float64}
+end
+
+struct RtTransform64
+    xform::NTuple{12,Float64}
+    inv_xform::NTuple{12,Float64}
+    bbox::NTuple{6,Float64}
+end
+
+struct RtMaterial64
+    type::Int32
+    texture::Int32
+    fuzz::Float64
+    eta::Float64
+end
+
+struct RtTexture64
+    kind::Int32
+    a::Int32
+    b::Int32
+    pad::Int32
+    color::NTuple{3,Float64}
+    scale::Float64
+end
+
+struct RtPerlin64
+    ranvec::NTuple{768,Float64}
+    perm_x::NTuple{256,Int32}
+    perm_y::NTuple{256,Int32}
+    perm_z::NTuple{256,Int32}
+end
+
+struct RtMesh64
+    n_vertices::Int32
+    n_triangles::Int32
+    n_materials::Int32
+    pad::Int32
+    vertices::Ptr{Float64}
+    indices::Ptr{Int32}
+    materials::Ptr{Int32}
+    tri_ids::Ptr{Int32}
+end
+
+struct RtBvh64
+    kind::Int32
+    n_objects::Int32
+    objects::Ptr{Int32}
+    n_nodes::Int32
+    pad::Int32
+    node_bounds::Ptr{Float64}
+    node_left::Ptr{Int32}
+    node_right::Ptr{Int32}
+    node_leaf::Ptr{UInt8}
+end
+
+struct RtSceneDesc64
+    n_objects::Int32
+    objects::Ptr{RtObject64}
+    n_top::Int32
+    top::Ptr{Int32}
+    n_transforms::Int32
+    transforms::Ptr{RtTransform64}
+    n_materials::Int32
+    materials::Ptr{RtMaterial64}
+    n_textures::Int32
+    textures::Ptr{RtTexture64}
+    n_images::Int32
+    images::Ptr{RtImage}
+    n_perlins::Int32
+    perlins::Ptr{RtPerlin64}
+    n_meshes::Int32
+    meshes::Ptr{RtMesh64}
+    n_groups::Int32
+    groups::Ptr{RtBvh64}
+    n_buckets::Int32
+    buckets::Ptr{RtBvh64}
+end
+
+# == Camera{Float64}
+struct RtCamera64
+    origin::NTuple{3,Float64}
+    lower_left_corner::NTuple{3,Float64}
+    horizontal::NTuple{3,Float64}
+    vertical::NTuple{3,Float64}
+    u::NTuple{3,Float64}
+    v::NTuple{3,Float64}
+    w::NTuple{3,Float64}
+    lens_radius::Float64
+    t0::Float64
+    t1::Float64
+end
+
+# the record types of an element type
+records(::Type{Float32}) = (object = RtObject, transform = RtTransform, material = RtMaterial, texture = RtTexture, perlin = RtPerlin,
+                            mesh = RtMesh, bvh = RtBvh, desc = RtSceneDesc)
+records(::Type{Float64}) = (object = RtObject64, transform = RtTransform64, material = RtMaterial64, texture = RtTexture64,
+                            perlin = RtPerlin64, mesh = RtMesh64, bvh = RtBvh64, desc = RtSceneDesc64)
+records(::Type{F}) where F = error("librt_amd: the GPU path renders in Float32 or Float64, not $F")
+
 struct RtStats
     seconds::Float64
     paths::UInt64

@@ -21,7 +21,10 @@ SCALARS = {"Int32": (4, 4), "UInt32": (4, 4), "Float32": (4, 4), "Float64": (8, 
            "UInt8": (1, 1), "Cint": (4, 4)}
 PAIRS = {"RtObject": "rtObject", "RtTransform": "rtTransform", "RtMaterial": "rtMaterial", "RtTexture": "rtTexture",
          "RtImage": "rtImage", "RtPerlin": "rtPerlin", "RtMesh": "rtMesh", "RtBvh": "rtBvh", "RtSceneDesc": "rtSceneDesc",
-         "RtCamera": "rtCamera", "RtStats": "rtStats"}
+         "RtCamera": "rtCamera", "RtStats": "rtStats",
+         "RtObject64": "rtObject64", "RtTransform64": "rtTransform64", "RtMaterial64": "rtMaterial64", "RtTexture64": "rtTexture64",
+         "RtPerlin64": "rtPerlin64", "RtMesh64": "rtMesh64", "RtBvh64": "rtBvh64", "RtSceneDesc64": "rtSceneDesc64",
+         "RtCamera64": "rtCamera64"}
 
 
 def julia_structs():
@@ -96,6 +99,7 @@ def test_julia_structs_match_the_header_and_ctypes(tmp_path):
             assert fsize == cf.size, (jl, name, fsize, cf.size)
     # Camera{Float32} (src/camera.jl:3-14: seven Vec3 and three scalars) is passed as it is where the library wants an rtCamera
     assert C.sizeof(ffi.rtCamera) == 7 * 12 + 3 * 4
+    assert C.sizeof(ffi.rtCamera64) == 7 * 24 + 3 * 8       # ... and Camera{Float64} an rtCamera64
 
 
 def julia_sources():
@@ -145,7 +149,7 @@ def test_every_ccall_names_a_declared_entry_point_with_matching_arguments():
                 else:
                     assert kind[p] is a, (fn, p, a)
     assert {"rt_scene_create", "rt_scene_destroy", "rt_render", "rt_group_create", "rt_group_render", "rt_group_destroy",
-            "rt_last_error", "rt_device_count"} <= seen
+            "rt_last_error", "rt_device_count", "rt_scene_create_f64", "rt_scene_destroy_f64", "rt_render_f64"} <= seen
 
 
 def strip_code(text):
