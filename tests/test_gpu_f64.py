@@ -58,6 +58,28 @@ def test_sample_scene_hits_paths_and_image(key):
         dev.close()
 
 
+@pytest.mark.parametrize("key,size,cols", [("cu_cover2", (200, 200), 6), ("cover2", (160, 160), 4), ("teapot", (320, 180), 4)])
+def test_larger_frames(key, size, cols):
+    """Frames large enough for several generations of paths per slot (path regeneration, the end of a batch) and, with
+    the small pool, for slots that are handed a new path many times."""
+    world, kw = rt.get_scene(key, spp=cols, F=F)
+    cam, pat, bg = kw["camera"], kw["pattern"], kw["background"]
+    W, Hh = size
+    want = O.OracleScene(world, F=F).render(cam, pat, bg, W, Hh)
+    dev = rt.DeviceScene(world, F=F)
+    try:
+        img, st = dev.render(cam, pat, bg, W, Hh)
+        assert (bits(img) != bits(want)).sum() == 0 and st.paths == W * Hh * cols
+        os.environ["RT_AMD_F64_SLOTS"] = "4096"
+        try:
+            img, _ = dev.render(cam, pat, bg, W, Hh)
+        finally:
+            del os.environ["RT_AMD_F64_SLOTS"]
+        assert (bits(img) != bits(want)).sum() == 0
+    finally:
+        dev.close()
+
+
 def test_float64_differs_from_float32_only_by_rounding_at_the_first_hit():
     """The two element types see the same scene: first hits agree in id, and in t to Float32 accuracy."""
     w32, kw32 = rt.get_scene("cornell_box", spp=1)
@@ -127,7 +149,7 @@ def test_bad_arguments_are_errors():
 
 
 # RT_AMD_FUZZ_SCENES_F64=N changes the size of the sweep
-@pytest.mark.parametrize("seed", range(1, 1 + int(os.environ.get("RT_AMD_FUZZ_SCENES_F64", "150"))))
+@pytest.mark.parametrize("seed", range(1, 1 + int(os.environ.get("RT_AMD_FUZZ_SCENES_F64", "400"))))
 def test_random_scene_f64(seed):
     from test_gpu_fuzz import random_scene
     with H.element_type(F):
