@@ -1106,8 +1106,10 @@ struct rtScene64 {
     unsigned long long* d_next = nullptr;
     real* d_pool = nullptr; size_t pool_cap = 0;      // the slots' real planes
     int32_t* d_pool_i = nullptr; size_t pool_i_cap = 0; // ... and int planes
-    uint32_t* d_live = nullptr;                        // R64_SYNC_EVERY counters of slots alive after a shade launch
+    uint32_t* d_live = nullptr;                        // per half pool R64_SYNC_EVERY counters of slots alive after a shade launch
     uint32_t* h_live = nullptr;                        // pinned mirror
+    hipStream_t side = nullptr;                        // the second half pool's stream
+    hipEvent_t fork = nullptr, join = nullptr;
     int n_cus = 0;
 };
 
@@ -1390,8 +1392,8 @@ int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n
     st = grow64(&s->d_radiance, &s->radiance_cap, (size_t)cols_per_batch * 3 * pixels);
     if (st != RT_OK) return st;
     if (!s->d_next) HIP_TRY64(hipMalloc((void**)&s->d_next, sizeof(unsigned long long)));
-    if (!s->d_live) HIP_TRY64(hipMalloc((void**)&s->d_live, R64_SYNC_EVERY * sizeof(uint32_t)));
-    if (!s->h_live) HIP_TRY64(hipHostMalloc((void**)&s->h_live, R64_SYNC_EVERY * sizeof(uint32_t)));
+    if (!s->d_live) HIP_TRY64(hipMalloc((void**)&s->d_live, 2 * R64_SYNC_EVERY * sizeof(uint32_t)));
+    if (!s->h_live) HIP_TRY64(hipHostMalloc((void**)&s->h_live, 2 * R64_SYNC_EVERY * sizeof(uint32_t)));
     uint32_t max_slots = R64_MAX_SLOTS;
     if (const char* e = getenv("RT_AMD_F64_SLOTS")) // for tests and tuning
         if (atoi(e) > 0) max_slots = (uint32_t)atoi(e);
@@ -1402,43 +1404,79 @@ int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n
     F.first = first; F.stride = stride;
     F.bg[0] = bg[0]; F.bg[1] = bg[1]; F.bg[2] = bg[2];
     F.seed32 = fold_seed(seed);
+    // Two half pools on two streams: a launch of the extend kernel ends with the few workgroups whose rays walk longest
+    // and the rest of the GPU idle; the other half's kernels fill that time.
+    int n_pools = 2;
+    if (const char* e = getenv("RT_AMD_F64_POOLS"))
+        if (atoi(e) == 1) n_pools = 1;
+    if (!s->side) {
+        HIP_TRY64(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        HIP_TRY64(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
+        HIP_TRY64(hipEventCreateWithFlags(&s->join, hipEventDisableTiming));
+    }
     for (int b0 = 0; b0 < count; b0 += cols_per_batch) {
         int cols = std::min(cols_per_batch, count - b0);
         F.batch_first = b0; F.batch_cols = cols;
         F.n_paths = (unsigned long long)cols * (unsigned long long)pixels;
-        Pool64 pool;
         // a pool an eighth of the batch (small frames: the launches at the end of a batch, when few slots still hold a
         // path, cost less), between 256 Ki and max_slots
         unsigned long long want_slots = std::max<unsigned long long>(F.n_paths / 8ull, 256ull << 10);
         want_slots = std::min<unsigned long long>(want_slots, F.n_paths);
-        pool.n_slots = (uint32_t)std::min<unsigned long long>((want_slots + R64_BLOCK - 1) / R64_BLOCK * R64_BLOCK, max_slots);
-        pool.pad = 0;
-        st = grow64(&s->d_pool, &s->pool_cap, (size_t)PD_PLANES * pool.n_slots);
-        if (st == RT_OK) st = grow64(&s->d_pool_i, &s->pool_i_cap, (size_t)PI_PLANES * pool.n_slots);
+        uint32_t total_slots = (uint32_t)std::min<unsigned long long>((want_slots + R64_BLOCK - 1) / R64_BLOCK * R64_BLOCK, max_slots);
+        const int pools = total_slots >= 4u * R64_BLOCK ? n_pools : 1;
+        const uint32_t per = (total_slots / pools + R64_BLOCK - 1) / R64_BLOCK * R64_BLOCK;
+        st = grow64(&s->d_pool, &s->pool_cap, (size_t)PD_PLANES * per * pools);
+        if (st == RT_OK) st = grow64(&s->d_pool_i, &s->pool_i_cap, (size_t)PI_PLANES * per * pools);
         if (st != RT_OK) return st;
-        pool.d = s->d_pool;
-        pool.i = s->d_pool_i;
-        const dim3 grid((pool.n_slots + R64_BLOCK - 1) / R64_BLOCK), block(R64_BLOCK);
+        Pool64 pool[2];
+        hipStream_t on[2] = {stream, s->side};
+        for (int h = 0; h < pools; ++h) {
+            pool[h].n_slots = per;
+            pool[h].pad = 0;
+            pool[h].d = s->d_pool + (size_t)h * PD_PLANES * per;
+            pool[h].i = s->d_pool_i + (size_t)h * PI_PLANES * per;
+        }
+        const dim3 grid((per + R64_BLOCK - 1) / R64_BLOCK), block(R64_BLOCK);
         HIP_TRY64(hipMemsetAsync(s->d_next, 0, sizeof(unsigned long long), stream));
-        HIP_TRY64(hipMemsetAsync(pool.i, 0, (size_t)pool.n_slots * sizeof(int32_t), stream)); // depth plane: every slot wants a path
-        HIP_TRY64(hipMemsetAsync(s->d_live, 0, R64_SYNC_EVERY * sizeof(uint32_t), stream));
-        hipLaunchKernelGGL(rt64_shade_kernel, grid, block, 0, stream, s->dev, F, pool, s->d_next, s->d_radiance, s->d_live); // the first paths
+        if (pools > 1) { // the side stream starts after what the caller's stream holds so far
+            HIP_TRY64(hipEventRecord(s->fork, stream));
+            HIP_TRY64(hipStreamWaitEvent(s->side, s->fork, 0));
+        }
+        for (int h = 0; h < pools; ++h) {
+            HIP_TRY64(hipMemsetAsync(pool[h].i, 0, (size_t)per * sizeof(int32_t), on[h])); // depth plane: every slot wants a path
+            HIP_TRY64(hipMemsetAsync(s->d_live + h * R64_SYNC_EVERY, 0, R64_SYNC_EVERY * sizeof(uint32_t), on[h]));
+            hipLaunchKernelGGL(rt64_shade_kernel, grid, block, 0, on[h], s->dev, F, pool[h], s->d_next, s->d_radiance, s->d_live + h * R64_SYNC_EVERY); // the first paths
+        }
         // every path ends within max_depth bounces of its start, and a launch that starts none ends the frame soon after:
         // the loop is bounded by the paths there are
-        const unsigned long long most = (F.n_paths / pool.n_slots + 2ull) * (unsigned long long)(max_depth + 1) + 8ull;
-        bool done = false;
-        for (unsigned long long it = 0; !done; it += R64_SYNC_EVERY) {
+        const unsigned long long most = (F.n_paths / per + 2ull) * (unsigned long long)(max_depth + 1) + 8ull;
+        bool done[2] = {false, pools < 2};
+        for (unsigned long long it = 0; !(done[0] && done[1]); it += R64_SYNC_EVERY) {
             if (it > most) return rt_fail(RT_EHIP, "rt_render_f64: the frame did not end within %llu bounces", most);
-            HIP_TRY64(hipMemsetAsync(s->d_live, 0, R64_SYNC_EVERY * sizeof(uint32_t), stream));
-            for (int k = 0; k < R64_SYNC_EVERY; ++k) {
-                if (s->dev.n_groups > 0) hipLaunchKernelGGL(rt64_extend_kernel<true>, grid, block, 0, stream, s->dev, F, pool);
-                else hipLaunchKernelGGL(rt64_extend_kernel<false>, grid, block, 0, stream, s->dev, F, pool);
-                hipLaunchKernelGGL(rt64_shade_kernel, grid, block, 0, stream, s->dev, F, pool, s->d_next, s->d_radiance, s->d_live + k);
-            }
+            for (int h = 0; h < pools; ++h)
+                if (!done[h]) HIP_TRY64(hipMemsetAsync(s->d_live + h * R64_SYNC_EVERY, 0, R64_SYNC_EVERY * sizeof(uint32_t), on[h]));
+            for (int k = 0; k < R64_SYNC_EVERY; ++k)
+                for (int h = 0; h < pools; ++h) {
+                    if (done[h]) continue;
+                    if (s->dev.n_groups > 0) hipLaunchKernelGGL(rt64_extend_kernel<true>, grid, block, 0, on[h], s->dev, F, pool[h]);
+                    else hipLaunchKernelGGL(rt64_extend_kernel<false>, grid, block, 0, on[h], s->dev, F, pool[h]);
+                    hipLaunchKernelGGL(rt64_shade_kernel, grid, block, 0, on[h], s->dev, F, pool[h], s->d_next, s->d_radiance,
+                                       s->d_live + h * R64_SYNC_EVERY + k);
+                }
             HIP_TRY64(hipGetLastError());
-            HIP_TRY64(hipMemcpyAsync(s->h_live, s->d_live, R64_SYNC_EVERY * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIP_TRY64(hipStreamSynchronize(stream));
-            done = s->h_live[R64_SYNC_EVERY - 1] == 0;
+            for (int h = 0; h < pools; ++h)
+                if (!done[h])
+                    HIP_TRY64(hipMemcpyAsync(s->h_live + h * R64_SYNC_EVERY, s->d_live + h * R64_SYNC_EVERY, R64_SYNC_EVERY * sizeof(uint32_t),
+                                             hipMemcpyDeviceToHost, on[h]));
+            for (int h = 0; h < pools; ++h) {
+                if (done[h]) continue;
+                HIP_TRY64(hipStreamSynchronize(on[h]));
+                done[h] = s->h_live[h * R64_SYNC_EVERY + R64_SYNC_EVERY - 1] == 0;
+            }
+        }
+        if (pools > 1) { // the caller's stream goes on after the side stream's last kernel
+            HIP_TRY64(hipEventRecord(s->join, s->side));
+            HIP_TRY64(hipStreamWaitEvent(stream, s->join, 0));
         }
         hipLaunchKernelGGL(rt64_sum_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, (const real*)s->d_radiance, cols, width,
                            height, b0 == 0 ? 1 : 0, d_accum);
@@ -1500,6 +1538,9 @@ extern "C" int rt_scene_destroy_f64(rtScene64* s) {
     if (s->d_pool_i) (void)hipFree(s->d_pool_i);
     if (s->d_live) (void)hipFree(s->d_live);
     if (s->h_live) (void)hipHostFree(s->h_live);
+    if (s->side) (void)hipStreamDestroy(s->side);
+    if (s->fork) (void)hipEventDestroy(s->fork);
+    if (s->join) (void)hipEventDestroy(s->join);
     delete s;
     return RT_OK;
 }
