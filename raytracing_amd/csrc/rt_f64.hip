@@ -1108,8 +1108,9 @@ struct rtScene64 {
     int32_t* d_pool_i = nullptr; size_t pool_i_cap = 0; // ... and int planes
     uint32_t* d_live = nullptr;                        // per half pool R64_SYNC_EVERY counters of slots alive after a shade launch
     uint32_t* h_live = nullptr;                        // pinned mirror
-    hipStream_t side = nullptr;                        // the second half pool's stream
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr}; // the streams of the pools after the first
+    hipEvent_t fork = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t read[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}}; // counters of a batch are on the host
     int n_cus = 0;
 };
 
@@ -1371,8 +1372,9 @@ int check_frame64(const char* who, rtScene64* s, const rtCamera64* cam, const re
 const size_t R64_RADIANCE_BUDGET = (size_t)8 << 30;
 
 // slots of the pool (156 bytes each); bounce launches between two looks at the live counter
-const uint32_t R64_MAX_SLOTS = 2u << 20;
+const uint32_t R64_MAX_SLOTS = 3u << 19; // 1.5 Mi: the best of 1, 1.5, 2, 3 and 4 Mi with four pools
 const int R64_SYNC_EVERY = 8;
+const int R64_MAX_POOLS = 4, R64_POOLS_DEFAULT = 4; // pools of slots, each on a stream of its own
 
 int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n, int first, int stride, const real* bg, int width, int height,
                  int max_depth, uint64_t seed, real* d_accum, hipStream_t stream) {
@@ -1392,8 +1394,8 @@ int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n
     st = grow64(&s->d_radiance, &s->radiance_cap, (size_t)cols_per_batch * 3 * pixels);
     if (st != RT_OK) return st;
     if (!s->d_next) HIP_TRY64(hipMalloc((void**)&s->d_next, sizeof(unsigned long long)));
-    if (!s->d_live) HIP_TRY64(hipMalloc((void**)&s->d_live, 2 * R64_SYNC_EVERY * sizeof(uint32_t)));
-    if (!s->h_live) HIP_TRY64(hipHostMalloc((void**)&s->h_live, 2 * R64_SYNC_EVERY * sizeof(uint32_t)));
+    if (!s->d_live) HIP_TRY64(hipMalloc((void**)&s->d_live, 2 * R64_MAX_POOLS * R64_SYNC_EVERY * sizeof(uint32_t)));
+    if (!s->h_live) HIP_TRY64(hipHostMalloc((void**)&s->h_live, 2 * R64_MAX_POOLS * R64_SYNC_EVERY * sizeof(uint32_t)));
     uint32_t max_slots = R64_MAX_SLOTS;
     if (const char* e = getenv("RT_AMD_F64_SLOTS")) // for tests and tuning
         if (atoi(e) > 0) max_slots = (uint32_t)atoi(e);
@@ -1406,14 +1408,18 @@ int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n
     F.seed32 = fold_seed(seed);
     // Two half pools on two streams: a launch of the extend kernel ends with the few workgroups whose rays walk longest
     // and the rest of the GPU idle; the other half's kernels fill that time.
-    int n_pools = 2;
+    int n_pools = R64_POOLS_DEFAULT;
     if (const char* e = getenv("RT_AMD_F64_POOLS"))
-        if (atoi(e) == 1) n_pools = 1;
-    if (!s->side) {
-        HIP_TRY64(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
-        HIP_TRY64(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
-        HIP_TRY64(hipEventCreateWithFlags(&s->join, hipEventDisableTiming));
-    }
+        if (atoi(e) >= 1 && atoi(e) <= R64_MAX_POOLS) n_pools = atoi(e);
+    for (int h = 1; h < n_pools; ++h)
+        if (!s->side[h]) {
+            HIP_TRY64(hipStreamCreateWithFlags(&s->side[h], hipStreamNonBlocking));
+            HIP_TRY64(hipEventCreateWithFlags(&s->join[h], hipEventDisableTiming));
+        }
+    if (!s->fork) HIP_TRY64(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
+    for (int h = 0; h < n_pools; ++h)
+        for (int q = 0; q < 2; ++q)
+            if (!s->read[h][q]) HIP_TRY64(hipEventCreateWithFlags(&s->read[h][q], hipEventDisableTiming));
     for (int b0 = 0; b0 < count; b0 += cols_per_batch) {
         int cols = std::min(cols_per_batch, count - b0);
         F.batch_first = b0; F.batch_cols = cols;
@@ -1423,13 +1429,15 @@ int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n
         unsigned long long want_slots = std::max<unsigned long long>(F.n_paths / 8ull, 256ull << 10);
         want_slots = std::min<unsigned long long>(want_slots, F.n_paths);
         uint32_t total_slots = (uint32_t)std::min<unsigned long long>((want_slots + R64_BLOCK - 1) / R64_BLOCK * R64_BLOCK, max_slots);
-        const int pools = total_slots >= 4u * R64_BLOCK ? n_pools : 1;
+        const int pools = total_slots >= 64u * R64_BLOCK ? n_pools : 1;
         const uint32_t per = (total_slots / pools + R64_BLOCK - 1) / R64_BLOCK * R64_BLOCK;
         st = grow64(&s->d_pool, &s->pool_cap, (size_t)PD_PLANES * per * pools);
         if (st == RT_OK) st = grow64(&s->d_pool_i, &s->pool_i_cap, (size_t)PI_PLANES * per * pools);
         if (st != RT_OK) return st;
-        Pool64 pool[2];
-        hipStream_t on[2] = {stream, s->side};
+        Pool64 pool[R64_MAX_POOLS];
+        hipStream_t on[R64_MAX_POOLS];
+        on[0] = stream;
+        for (int h = 1; h < pools; ++h) on[h] = s->side[h];
         for (int h = 0; h < pools; ++h) {
             pool[h].n_slots = per;
             pool[h].pad = 0;
@@ -1438,45 +1446,55 @@ int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n
         }
         const dim3 grid((per + R64_BLOCK - 1) / R64_BLOCK), block(R64_BLOCK);
         HIP_TRY64(hipMemsetAsync(s->d_next, 0, sizeof(unsigned long long), stream));
-        if (pools > 1) { // the side stream starts after what the caller's stream holds so far
+        if (pools > 1) { // the side streams start after what the caller's stream holds so far
             HIP_TRY64(hipEventRecord(s->fork, stream));
-            HIP_TRY64(hipStreamWaitEvent(s->side, s->fork, 0));
+            for (int h = 1; h < pools; ++h) HIP_TRY64(hipStreamWaitEvent(s->side[h], s->fork, 0));
         }
         for (int h = 0; h < pools; ++h) {
             HIP_TRY64(hipMemsetAsync(pool[h].i, 0, (size_t)per * sizeof(int32_t), on[h])); // depth plane: every slot wants a path
-            HIP_TRY64(hipMemsetAsync(s->d_live + h * R64_SYNC_EVERY, 0, R64_SYNC_EVERY * sizeof(uint32_t), on[h]));
-            hipLaunchKernelGGL(rt64_shade_kernel, grid, block, 0, on[h], s->dev, F, pool[h], s->d_next, s->d_radiance, s->d_live + h * R64_SYNC_EVERY); // the first paths
+            hipLaunchKernelGGL(rt64_shade_kernel, grid, block, 0, on[h], s->dev, F, pool[h], s->d_next, s->d_radiance,
+                               s->d_live + (h * 2 + 1) * R64_SYNC_EVERY); // the first paths (its count is not read)
         }
         // every path ends within max_depth bounces of its start, and a launch that starts none ends the frame soon after:
         // the loop is bounded by the paths there are
         const unsigned long long most = (F.n_paths / per + 2ull) * (unsigned long long)(max_depth + 1) + 8ull;
-        bool done[2] = {false, pools < 2};
-        for (unsigned long long it = 0; !(done[0] && done[1]); it += R64_SYNC_EVERY) {
+        // The host looks at a pool's counters one batch of launches late: batch i + 1 is in the stream before the host
+        // waits for batch i, so a stream never runs dry while the host reads (the batch launched after a pool's last
+        // live path finds every slot idle and costs a few empty launches).  Counters: [pool][batch parity][launch].
+        bool done[R64_MAX_POOLS];
+        for (int h = 0; h < R64_MAX_POOLS; ++h) done[h] = h >= pools;
+        auto all_done = [&]() { for (int h = 0; h < pools; ++h) if (!done[h]) return false; return true; };
+        auto live_at = [&](uint32_t* base, int h, int parity) { return base + (h * 2 + parity) * R64_SYNC_EVERY; };
+        for (unsigned long long it = 0, batch = 0; !all_done(); it += R64_SYNC_EVERY, ++batch) {
             if (it > most) return rt_fail(RT_EHIP, "rt_render_f64: the frame did not end within %llu bounces", most);
+            const int parity = (int)(batch & 1ull);
             for (int h = 0; h < pools; ++h)
-                if (!done[h]) HIP_TRY64(hipMemsetAsync(s->d_live + h * R64_SYNC_EVERY, 0, R64_SYNC_EVERY * sizeof(uint32_t), on[h]));
+                if (!done[h]) HIP_TRY64(hipMemsetAsync(live_at(s->d_live, h, parity), 0, R64_SYNC_EVERY * sizeof(uint32_t), on[h]));
             for (int k = 0; k < R64_SYNC_EVERY; ++k)
                 for (int h = 0; h < pools; ++h) {
                     if (done[h]) continue;
                     if (s->dev.n_groups > 0) hipLaunchKernelGGL(rt64_extend_kernel<true>, grid, block, 0, on[h], s->dev, F, pool[h]);
                     else hipLaunchKernelGGL(rt64_extend_kernel<false>, grid, block, 0, on[h], s->dev, F, pool[h]);
                     hipLaunchKernelGGL(rt64_shade_kernel, grid, block, 0, on[h], s->dev, F, pool[h], s->d_next, s->d_radiance,
-                                       s->d_live + h * R64_SYNC_EVERY + k);
+                                       live_at(s->d_live, h, parity) + k);
                 }
             HIP_TRY64(hipGetLastError());
-            for (int h = 0; h < pools; ++h)
-                if (!done[h])
-                    HIP_TRY64(hipMemcpyAsync(s->h_live + h * R64_SYNC_EVERY, s->d_live + h * R64_SYNC_EVERY, R64_SYNC_EVERY * sizeof(uint32_t),
-                                             hipMemcpyDeviceToHost, on[h]));
             for (int h = 0; h < pools; ++h) {
                 if (done[h]) continue;
-                HIP_TRY64(hipStreamSynchronize(on[h]));
-                done[h] = s->h_live[h * R64_SYNC_EVERY + R64_SYNC_EVERY - 1] == 0;
+                HIP_TRY64(hipMemcpyAsync(live_at(s->h_live, h, parity), live_at(s->d_live, h, parity), R64_SYNC_EVERY * sizeof(uint32_t),
+                                         hipMemcpyDeviceToHost, on[h]));
+                HIP_TRY64(hipEventRecord(s->read[h][parity], on[h]));
+            }
+            if (batch == 0) continue;
+            for (int h = 0; h < pools; ++h) { // the batch before this one
+                if (done[h]) continue;
+                HIP_TRY64(hipEventSynchronize(s->read[h][parity ^ 1]));
+                done[h] = live_at(s->h_live, h, parity ^ 1)[R64_SYNC_EVERY - 1] == 0;
             }
         }
-        if (pools > 1) { // the caller's stream goes on after the side stream's last kernel
-            HIP_TRY64(hipEventRecord(s->join, s->side));
-            HIP_TRY64(hipStreamWaitEvent(stream, s->join, 0));
+        for (int h = 1; h < pools; ++h) { // the caller's stream goes on after the side streams' last kernels
+            HIP_TRY64(hipEventRecord(s->join[h], s->side[h]));
+            HIP_TRY64(hipStreamWaitEvent(stream, s->join[h], 0));
         }
         hipLaunchKernelGGL(rt64_sum_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, (const real*)s->d_radiance, cols, width,
                            height, b0 == 0 ? 1 : 0, d_accum);
@@ -1538,9 +1556,13 @@ extern "C" int rt_scene_destroy_f64(rtScene64* s) {
     if (s->d_pool_i) (void)hipFree(s->d_pool_i);
     if (s->d_live) (void)hipFree(s->d_live);
     if (s->h_live) (void)hipHostFree(s->h_live);
-    if (s->side) (void)hipStreamDestroy(s->side);
+    for (int h = 0; h < 4; ++h) {
+        if (s->side[h]) (void)hipStreamDestroy(s->side[h]);
+        if (s->join[h]) (void)hipEventDestroy(s->join[h]);
+        for (int q = 0; q < 2; ++q)
+            if (s->read[h][q]) (void)hipEventDestroy(s->read[h][q]);
+    }
     if (s->fork) (void)hipEventDestroy(s->fork);
-    if (s->join) (void)hipEventDestroy(s->join);
     delete s;
     return RT_OK;
 }
