@@ -203,7 +203,7 @@ def main():
                                                   "size": "%dx%d" % (k2["width"], k2["height"])}
                 sc2.close()
             # the Float64 mode (render(Float64, ...)): the same scene with double tables through rt_*_f64, a tenth of the
-            # columns (it walks the reference's own trees in double: about a ninth of the Float32 path's rate)
+            # columns (it walks the reference's own trees in double: about a sixth of the Float32 path's rate)
             f64_cols = max(1, n // 10)
             w3, k3 = rt.get_scene(args.scene, spp=f64_cols, F=np.float64)
             sc3 = rt.DeviceScene(w3, device=local_rank, F=np.float64)
