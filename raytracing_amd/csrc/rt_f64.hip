@@ -1374,7 +1374,8 @@ const size_t R64_RADIANCE_BUDGET = (size_t)8 << 30;
 // slots of the pool (156 bytes each); bounce launches between two looks at the live counter
 const uint32_t R64_MAX_SLOTS = 3u << 19; // 1.5 Mi: the best of 1, 1.5, 2, 3 and 4 Mi with four pools
 const int R64_SYNC_EVERY = 8;
-const int R64_MAX_POOLS = 4, R64_POOLS_DEFAULT = 4; // pools of slots, each on a stream of its own
+const int R64_MAX_POOLS = 4, R64_POOLS_DEFAULT = 3; // pools of slots, each on a stream of its own (three: with the caller's
+                                                    // stream that leaves one of the four hardware queues of a process to others; a fifth stream made four pools lose a quarter)
 
 int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n, int first, int stride, const real* bg, int width, int height,
                  int max_depth, uint64_t seed, real* d_accum, hipStream_t stream) {
