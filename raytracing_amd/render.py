@@ -207,17 +207,17 @@ class DeviceScene:
         render()), state a dict of host arrays {"accum", "next", "passes", "n", "done"} that np.savez can store and a
         later call takes back through `state=` to go on where it stopped.  After the last shard the image equals
         render()'s up to the order of the float32 sums."""
-        self._f32_only("render_progressive()")
         import torch
         if not torch.cuda.is_available():
             raise ffi.RtError("render_progressive keeps its accumulators in torch tensors and torch sees no GPU; if the "
                               "library was loaded first, import torch before raytracing_amd (torch ships its own HIP "
                               "runtime, which cannot start after the system's)")
-        pat, n = _pattern(pattern)
+        F = self.F
+        pat, n = _pattern(pattern, F)
         passes = max(1, min(int(passes), n))
         dev = torch.device("cuda", torch.cuda.current_device())
         stream = torch.cuda.current_stream().cuda_stream
-        total = torch.zeros(3 * width * height, dtype=torch.float32, device=dev)
+        total = torch.zeros(3 * width * height, dtype=torch.float64 if F is np.float64 else torch.float32, device=dev)
         first, done = 0, 0
         if state is not None:
             if int(state["passes"]) != passes or int(state["n"]) != n or np.asarray(state["accum"]).size != total.numel():

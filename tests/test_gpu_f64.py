@@ -130,6 +130,29 @@ def test_batches_and_shards_sum_like_one_frame(monkeypatch):
         dev.close()
 
 
+def test_progressive_rendering_and_resume_in_float64(tmp_path):
+    """render_progressive on a Float64 scene: the accumulator, the state that np.savez stores and the pictures are
+    double; the last picture is the one-shot picture up to the order of the sums, interrupted or not."""
+    world, kw = rt.get_scene("cornell_box", spp=12, F=F)
+    cam, pat, bg = kw["camera"], kw["pattern"], kw["background"]
+    W, Hh = 40, 32
+    dev = rt.DeviceScene(world, F=F)
+    try:
+        full, _ = dev.render(cam, pat, bg, W, Hh)
+        steps = list(dev.render_progressive(cam, pat, bg, W, Hh, passes=3))
+        assert [s["done"] for s, _ in steps] == [4, 8, 12] and steps[-1][1].dtype == F and steps[-1][0]["accum"].dtype == F
+        np.testing.assert_allclose(steps[-1][1], full, rtol=1e-13, atol=1e-300)
+        gen = dev.render_progressive(cam, pat, bg, W, Hh, passes=3)
+        state, _ = next(gen)
+        gen.close()
+        np.savez(tmp_path / "state.npz", **state)
+        rest = list(dev.render_progressive(cam, pat, bg, W, Hh, passes=3, state=dict(np.load(tmp_path / "state.npz"))))
+        assert [s["done"] for s, _ in rest] == [8, 12]
+        np.testing.assert_array_equal(bits(rest[-1][1]), bits(steps[-1][1]))
+    finally:
+        dev.close()
+
+
 def test_bad_arguments_are_errors():
     from raytracing_amd import _ffi as ffi
     world, kw = rt.get_scene("cornell_box", spp=2, F=F)
