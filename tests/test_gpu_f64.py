@@ -130,6 +130,67 @@ def test_batches_and_shards_sum_like_one_frame(monkeypatch):
         dev.close()
 
 
+def test_edge_cases():
+    """smallest legal image, one pattern column, the MSAA table as pattern, depth limits 0, 1, 2, another seed"""
+    world, kw = rt.get_scene("cornell_smoke_box", spp=5, F=F)
+    cam, pat, bg = kw["camera"], kw["pattern"], kw["background"]
+    ref = O.OracleScene(world, F=F)
+    dev = rt.DeviceScene(world, F=F)
+    try:
+        with H.element_type(F):
+            msaa = H.MSAA_S16.astype(F)
+        for W, Hh, p, depth in ((2, 2, pat[:, :1], 50), (9, 3, msaa, 50), (16, 16, pat, 1), (16, 16, pat, 2), (8, 8, pat, 0)):
+            img, _ = dev.render(cam, p, bg, W, Hh, max_depth=depth)
+            np.testing.assert_array_equal(bits(img), bits(ref.render(cam, p, bg, W, Hh, max_depth=depth)))
+        a, _ = dev.render(cam, pat, bg, 24, 16, seed=7)
+        b, _ = dev.render(cam, pat, bg, 24, 16, seed=7)
+        c, _ = dev.render(cam, pat, bg, 24, 16)
+        np.testing.assert_array_equal(bits(a), bits(b))
+        assert not np.array_equal(a, c)
+        np.testing.assert_array_equal(bits(a), bits(ref.render(cam, pat, bg, 24, 16, seed=7)))
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("key", ["cornell_box", "cu_cover2", "cover2", "teapot"])
+def test_degenerate_rays_terminate_and_match(key):
+    """zero, axis-parallel, huge, infinite and NaN ray components (the box test by reciprocals hands those to the
+    divisions), rays that start on coordinate planes, nearly axis-parallel rays: every walk ends and gives the
+    oracle's hit"""
+    world, kw = rt.get_scene(key, spp=1, F=F)
+    cam = kw["camera"]
+    ref = O.OracleScene(world, F=F)
+    dev = rt.DeviceScene(world, F=F)
+    try:
+        base = O.primary_rays(cam, 8, 8, 8, 8, F=F)
+        o = base[0, :3].copy()
+        rays = []
+        for d in ([0, 0, 0], [1, 0, 0], [0, -1, 0], [0, 0, 1], [1e300, 1e300, 1e300], [1e-300, -1e-300, 1e-300], [-0.0, 0.0, -1.0],
+                  [np.inf, 0, 0], [np.nan, 1, 0], [np.nan, np.nan, np.nan], [1, np.inf, -np.inf]):
+            rays.append(np.concatenate([o, np.asarray(d, F), [0.5]]))
+        for oo in ([np.nan, 0, 0], [np.inf, 0, 0], [1e300, -1e300, 0], [0, 0, 0]):
+            rays.append(np.concatenate([np.asarray(oo, F), base[5, 3:6], [0.5]]))
+        rng = np.random.default_rng(11)
+        centre = base[:, :3].mean(axis=0) + base[:, 3:6].mean(axis=0)
+        for k in range(400):
+            src = base[rng.integers(len(base))]
+            oo = src[:3].copy() if k % 2 else src[:3] + src[3:6] * rng.uniform(0.2, 1.5)
+            d = centre - oo + rng.normal(0, 1, 3) * np.abs(centre - oo).max() if k % 2 == 0 else src[3:6].copy()
+            for axis in rng.choice(3, size=rng.integers(1, 3), replace=False):
+                d[axis] *= 10.0 ** -float(rng.integers(4, 300))
+            if k % 7 == 0:
+                oo[rng.integers(3)] = 0.0
+            rays.append(np.concatenate([oo, d, [rng.uniform()]]))
+        rays = np.array(rays, dtype=F)
+        a, b = ref.trace_rays(rays), dev.trace_rays(rays)
+        same = (a["prim_id"] == b["prim_id"]) & (a["sub_id"] == b["sub_id"]) & (bits(a["t"]) == bits(b["t"]))
+        assert same.all(), np.flatnonzero(~same)[:10]
+        hit = a["prim_id"] >= 0
+        np.testing.assert_array_equal(bits(a["normal"])[hit], bits(b["normal"])[hit])
+    finally:
+        dev.close()
+
+
 def test_progressive_rendering_and_resume_in_float64(tmp_path):
     """render_progressive on a Float64 scene: the accumulator, the state that np.savez stores and the pictures are
     double; the last picture is the one-shot picture up to the order of the sums, interrupted or not."""
