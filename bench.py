@@ -30,6 +30,7 @@ COST = {
     "lambertian": (29, 0), "metal": (42, 0), "dielectric": (45, 0), "isotropic": (17, 0), "emissive": (0, 0),
 }
 PEAK_FP32_TFLOPS = 157.3  # MI355X FP32 vector peak (spec), the compute roof of this kernel
+PEAK_FP64_TFLOPS = 78.6   # MI355X FP64 vector peak (spec), for the Float64 mode
 
 
 def algorithmic_work(st):
@@ -216,9 +217,16 @@ def main():
                 sc3.finalize(acc3.data_ptr(), f64_cols, W, H, acc3.data_ptr(), stream=stream)
                 torch.cuda.synchronize()
                 best = time.perf_counter() - t1
-            other["%s %d spp float64" % (args.scene, f64_cols)] = {
-                "Mpaths_per_s": W * H * f64_cols / best / 1e6, "s_per_frame": best, "paths": W * H * f64_cols,
-                "size": "%dx%d" % (W, H), "dtype": "f64"}
+            f64 = {"Mpaths_per_s": W * H * f64_cols / best / 1e6, "s_per_frame": best, "paths": W * H * f64_cols,
+                   "size": "%dx%d" % (W, H), "dtype": "f64"}
+            if roofline is not None:
+                # the same algorithmic work per path (the events of the reference algorithm, counted on the Float32 scene:
+                # the Float64 scene draws its random parts from the same stream two words at a time) against the FP64
+                # vector peak; whole frame (extend + shade), wall clock
+                tf = roofline["flops_per_path_incl_shading"] * W * H * f64_cols / best / 1e12
+                f64["roofline"] = {"bound": "valu", "achieved": tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_TFLOPS,
+                                   "kernel": "rt64_extend_kernel + rt64_shade_kernel (whole frame)"}
+            other["%s %d spp float64" % (args.scene, f64_cols)] = f64
             sc3.close()
             line["other_configs"] = other
         print(json.dumps(line), flush=True)
