@@ -335,7 +335,7 @@ int rt_perlin_generate(uint32_t seed, uint64_t* counter, int32_t vector, rtPerli
  * them.  The device then walks the reference's own trees (the ones in the description, one per type group) with the
  * reference's own box test in double, so results equal the CPU path's for Float64 bit for bit (random numbers: 53
  * bits from two words of the same counter-based generator).  Image buffers are double: the memory order of a Julia
- * Array{RGB{Float64},2}(H, W).  Unsupported nestings are the Float32 path's (RT_EUNSUPPORTED); in addition the trees
+ * Array{RGB{Float64},2}(H, W).  One process can drive several GPUs (rt_group_*_f64).  Unsupported nestings are the Float32 path's (RT_EUNSUPPORTED); in addition the trees
  * may need at most 40 stack entries per walk (a tree of meshes: its two levels together), which holds for any tree the
  * reference's median split builds over fewer than 2^30 objects. */
 typedef struct rtObject64 { int32_t kind, material, child, aux; double p[12]; } rtObject64;     /* as rtObject */
@@ -396,6 +396,15 @@ int rt_trace_rays_f64(rtScene64* scene, const double* rays, int n, double t_min,
                       int32_t* prim_id, int32_t* sub_id, double* t, double* normal, double* uv, uint8_t* front);
 int rt_trace_paths_f64(rtScene64* scene, const rtCamera64* camera, const double* pattern, int n, const double background[3],
                        int width, int height, int max_depth, uint64_t seed, const int32_t* ids, int n_paths, double* radiance);
+/* rt_group_* for Float64 scenes: one host process, several GPUs, the pattern columns dealt to them, the double
+ * accumulators summed on the first device (ncclReduce of ncclDouble, or peer copies and adds: RT_AMD_REDUCE=peer or a
+ * device listed twice).  A group of one device renders exactly what rt_render_f64 renders. */
+typedef struct rtGroup64 rtGroup64;
+int rt_group_create_f64(const rtSceneDesc64* desc, const int* devices, int n_devices, rtGroup64** out);
+int rt_group_size_f64(const rtGroup64* group, int* n_devices);
+int rt_group_render_f64(rtGroup64* group, const rtCamera64* camera, const double* pattern, int n, const double background[3],
+                        int width, int height, int max_depth, uint64_t seed, uint32_t flags, double* out, rtStats* stats);
+int rt_group_destroy_f64(rtGroup64* group);
 /* build_bvh (src/BVH.jl:65-109, src/mesh.jl:217-305) over Float64 boxes and vertices, as rt_bvh_build / rt_bvh_build_meshes */
 int rt_bvh_build_f64(int n, const double* object_bounds, int32_t* order, double* node_bounds, int32_t* node_left,
                      int32_t* node_right, uint8_t* node_leaf);

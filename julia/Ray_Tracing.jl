@@ -5,7 +5,7 @@
 # (Project.toml: CUDA and Adapt out, Libdl in).  julia/apply_overlay.py makes those edits to a checkout of the reference.
 #
 # The device path works in Float32 (the reference's default, main.jl:46,83,96) and in Float64 (render(Float64, ...),
-# main.jl:21: the rt_*_f64 entry points, on one GPU).
+# main.jl:21: the rt_*_f64 entry points).
 
 "Image on the GPU side of render(): what `CUDA.zeros(RGB{F}, height, width)` was (main.jl:35).  The pixels live in host
 memory the library writes into; the type only selects the method of draw!."
@@ -55,26 +55,32 @@ function draw!(img::DeviceImage{Float32}, world::SceneManager, camera::Camera{Fl
 end
 
 """
-    draw!(img::DeviceImage{Float64}, world::SceneManager, camera; background, pattern, seed)
+    draw!(img::DeviceImage{Float64}, world::SceneManager, camera; background, pattern, seed, devices)
 
 The same for `render(Float64, ...; gpu = true)`: the trees of `build_bvh(world)` go to the library as they are, in
-double, and rt_render_f64 walks them as the CPU path does (src/BVH.jl:22-53); one GPU.
+double, and rt_render_f64 (rt_group_render_f64 with `devices`) walks them as the CPU path does (src/BVH.jl:22-53).
 """
 function draw!(img::DeviceImage{Float64}, world::SceneManager, camera::Camera{Float64};
                background::Vec3{Float64} = zero(Vec3{Float64}), pattern::Array{Float64,2} = Float64.(MSAA_S16),
                seed::Integer = 0x5EED, devices::Union{Nothing,Vector{<:Integer}} = nothing, max_depth::Integer = 50)
     height, width = size(img)
     bvh = build_bvh(world)
-    scene = CuSceneManager(bvh; devices = devices)      # (a Float64 scene with `devices` is an error there)
+    scene = CuSceneManager(bvh; devices = devices)
     bg = Float64[background.x, background.y, background.z]
     cam = Ref(camera)                                   # Camera{Float64} has the layout of rtCamera64
     pixels = img.pixels
     try
         GC.@preserve pixels pattern bg begin
-            check(ccall((:rt_render_f64, librt), Cint,
-                        (Ptr{Cvoid}, Ref{Camera{Float64}}, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Cint, Cint, UInt64, UInt32, Ptr{Float64}, Ptr{Cvoid}),
-                        scene.handle, cam, pattern, size(pattern, 2), bg, width, height, max_depth, UInt64(seed), UInt32(0),
-                        Ptr{Float64}(pointer(pixels)), C_NULL))
+            out = Ptr{Float64}(pointer(pixels))
+            if devices === nothing
+                check(ccall((:rt_render_f64, librt), Cint,
+                            (Ptr{Cvoid}, Ref{Camera{Float64}}, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Cint, Cint, UInt64, UInt32, Ptr{Float64}, Ptr{Cvoid}),
+                            scene.handle, cam, pattern, size(pattern, 2), bg, width, height, max_depth, UInt64(seed), UInt32(0), out, C_NULL))
+            else
+                check(ccall((:rt_group_render_f64, librt), Cint,
+                            (Ptr{Cvoid}, Ref{Camera{Float64}}, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Cint, Cint, UInt64, UInt32, Ptr{Float64}, Ptr{Cvoid}),
+                            scene.handle, cam, pattern, size(pattern, 2), bg, width, height, max_depth, UInt64(seed), UInt32(0), out, C_NULL))
+            end
         end
     finally
         close(scene)

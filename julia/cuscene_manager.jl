@@ -6,7 +6,7 @@ include("cuBVH.jl")
 include("scene_manager.jl") # the reference's own file, unchanged (src/scene_manager.jl)
 
 mutable struct CuSceneManager
-    handle::Ptr{Cvoid}          # rtScene* (device == -1: rtGroup*, several GPUs); rtScene64* for a Float64 scene
+    handle::Ptr{Cvoid}          # rtScene* (device == -1: rtGroup*, several GPUs); rtScene64* / rtGroup64* for a Float64 scene
     device::Int
     F::DataType                 # element type of the scene: Float32 or Float64
 end
@@ -198,9 +198,12 @@ function CuSceneManager(bvh::Tuple; device::Integer = 0, devices::Union{Nothing,
     F = element_type(bvh[1])
     handle = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve keep begin
-        if F === Float64
-            devices === nothing || error("librt_amd: several GPUs in one process (rt_group_*) exist for Float32 scenes only")
+        if F === Float64 && devices === nothing
             check(ccall((:rt_scene_create_f64, librt), Cint, (Ref{RtSceneDesc64}, Cint, Ref{Ptr{Cvoid}}), desc, device, handle))
+        elseif F === Float64
+            list = Cint.(devices)
+            check(ccall((:rt_group_create_f64, librt), Cint, (Ref{RtSceneDesc64}, Ptr{Cint}, Cint, Ref{Ptr{Cvoid}}), desc,
+                        isempty(list) ? C_NULL : pointer(list), length(list), handle))
         elseif devices === nothing
             check(ccall((:rt_scene_create, librt), Cint, (Ref{RtSceneDesc}, Cint, Ref{Ptr{Cvoid}}), desc, device, handle))
         else
@@ -216,8 +219,10 @@ end
 
 function Base.close(scene::CuSceneManager)
     if scene.handle != C_NULL
-        if scene.F === Float64
+        if scene.F === Float64 && scene.device >= 0
             ccall((:rt_scene_destroy_f64, librt), Cint, (Ptr{Cvoid},), scene.handle)
+        elseif scene.F === Float64
+            ccall((:rt_group_destroy_f64, librt), Cint, (Ptr{Cvoid},), scene.handle)
         elseif scene.device >= 0
             ccall((:rt_scene_destroy, librt), Cint, (Ptr{Cvoid},), scene.handle)
         else

@@ -238,6 +238,11 @@ SYMBOLS = {
                                     c_f64p, c_f64p, c_f64p, c_u8p]),
     "rt_trace_paths_f64": (C.c_int, [C.c_void_p, C.POINTER(rtCamera64), c_f64p, C.c_int, c_f64p, C.c_int, C.c_int, C.c_int,
                                      C.c_uint64, c_i32p, C.c_int, c_f64p]),
+    "rt_group_create_f64": (C.c_int, [C.POINTER(rtSceneDesc64), c_i32p, C.c_int, C.POINTER(C.c_void_p)]),
+    "rt_group_size_f64": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "rt_group_render_f64": (C.c_int, [C.c_void_p, C.POINTER(rtCamera64), c_f64p, C.c_int, c_f64p, C.c_int, C.c_int, C.c_int,
+                                      C.c_uint64, C.c_uint32, c_f64p, C.POINTER(rtStats)]),
+    "rt_group_destroy_f64": (C.c_int, [C.c_void_p]),
     "rt_bvh_build_f64": (C.c_int, [C.c_int, c_f64p, c_i32p, c_f64p, c_i32p, c_i32p, c_u8p]),
     "rt_bvh_build_meshes_f64": (C.c_int, [C.c_int, c_i32p, C.POINTER(c_f64p), c_i32p, C.POINTER(c_i32p),
                                           C.POINTER(c_i32p), c_i32p, c_f64p, c_i32p, c_i32p, c_u8p]),

@@ -1056,6 +1056,10 @@ __global__ void rt64_sum_kernel(const real* radiance, int batch_cols, int width,
     }
     accum[out] = cx; accum[out + 1] = cy; accum[out + 2] = cz;
 }
+__global__ void rt64_add_kernel(real* dst, const real* src, size_t n) { // the sum of two accumulators (rt_group_render_f64)
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) dst[k] = dst[k] + src[k];
+}
 __global__ void rt64_finalize_kernel(const real* accum, real inv_n, size_t count, real* out) { // src/Ray_Tracing.jl:90-91
     size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < count) out[k] = sqrt(accum[k] * inv_n);
@@ -1505,6 +1509,10 @@ int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n
 }
 
 } // namespace
+
+extern "C" void rt64_launch_add(double* d_dst, const double* d_src, size_t n, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(rt64_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_dst, d_src, n);
+}
 
 extern "C" int rt_scene_create_f64(const rtSceneDesc64* desc, int device, rtScene64** out) {
     if (!desc || !out) return rt_fail(RT_EINVAL, "rt_scene_create_f64: null argument");

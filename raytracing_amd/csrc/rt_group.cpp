@@ -65,18 +65,52 @@ const Rccl* rccl() {
     return &g_rccl;
 }
 
-} // namespace
+// What differs between the two element types of render(F, ...) (main.jl:21): the records, the entry points of one
+// scene on one GPU, the kernel that adds two accumulators and the RCCL data type.
+struct Float32Path {
+    typedef float real;
+    typedef rtScene Scene;
+    typedef rtSceneDesc Desc;
+    typedef rtCamera Camera;
+    static const char* name() { return "rt_group_render"; }
+    static int create(const Desc* d, int device, Scene** s) { return rt_scene_create(d, device, s); }
+    static int destroy(Scene* s) { return rt_scene_destroy(s); }
+    static int accumulate(Scene* s, const Camera* c, const real* pattern, int n, int first, int stride, const real* bg, int w, int h, int depth,
+                          uint64_t seed, uint32_t flags, real* accum, hipStream_t stream) {
+        return rt_render_accumulate(s, c, pattern, n, first, stride, bg, w, h, depth, seed, flags & ~RT_FLAG_TIMING, accum, stream);
+    }
+    static int finalize(Scene* s, const real* accum, int n, int w, int h, real* out, hipStream_t stream) { return rt_finalize(s, accum, n, w, h, out, stream); }
+    static void add(real* dst, const real* src, size_t n, hipStream_t stream) { rt_launch_add(dst, src, n, stream); }
+    static ncclDataType_t nccl_type() { return ncclFloat; }
+};
+struct Float64Path {
+    typedef double real;
+    typedef rtScene64 Scene;
+    typedef rtSceneDesc64 Desc;
+    typedef rtCamera64 Camera;
+    static const char* name() { return "rt_group_render_f64"; }
+    static int create(const Desc* d, int device, Scene** s) { return rt_scene_create_f64(d, device, s); }
+    static int destroy(Scene* s) { return rt_scene_destroy_f64(s); }
+    static int accumulate(Scene* s, const Camera* c, const real* pattern, int n, int first, int stride, const real* bg, int w, int h, int depth,
+                          uint64_t seed, uint32_t, real* accum, hipStream_t stream) {
+        return rt_render_accumulate_f64(s, c, pattern, n, first, stride, bg, w, h, depth, seed, accum, stream);
+    }
+    static int finalize(Scene* s, const real* accum, int n, int w, int h, real* out, hipStream_t stream) { return rt_finalize_f64(s, accum, n, w, h, out, stream); }
+    static void add(real* dst, const real* src, size_t n, hipStream_t stream) { rt64_launch_add(dst, src, n, stream); }
+    static ncclDataType_t nccl_type() { return ncclDouble; }
+};
 
-struct rtGroup {
+template <class P>
+struct Group {
     std::vector<int> devices;
-    std::vector<rtScene*> scenes;
+    std::vector<typename P::Scene*> scenes;
     std::vector<hipStream_t> streams;
-    std::vector<float*> accum;        // per member: 3 * H * W floats on its device
+    std::vector<typename P::real*> accum; // per member: 3 * H * W numbers on its device
     std::vector<size_t> accum_cap;
-    float* stage = nullptr;           // on the first device: where a peer's accumulator lands before it is added
+    typename P::real* stage = nullptr;    // on the first device: where a peer's accumulator lands before it is added
     size_t stage_cap = 0;
-    std::vector<ncclComm_t> comms;    // one per member once the group has reduced over RCCL
-    bool distinct = true;             // no device appears twice (RCCL needs that)
+    std::vector<ncclComm_t> comms;        // one per member once the group has reduced over RCCL
+    bool distinct = true;                 // no device appears twice (RCCL needs that)
 };
 
 #define GROUP_HIP(expr)                                                                                  \
@@ -86,9 +120,8 @@ struct rtGroup {
             return rt_fail(e_ == hipErrorOutOfMemory ? RT_ENOMEM : RT_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-extern "C" {
-
-int rt_group_destroy(rtGroup* g) {
+template <class P>
+int group_destroy(Group<P>* g) {
     if (!g) return RT_OK;
     const Rccl* R = g->comms.empty() ? nullptr : rccl();
     for (size_t k = 0; k < g->devices.size(); ++k) {
@@ -96,21 +129,22 @@ int rt_group_destroy(rtGroup* g) {
         if (k < g->comms.size() && g->comms[k] && R && R->CommDestroy) (void)R->CommDestroy(g->comms[k]);
         if (k < g->accum.size() && g->accum[k]) (void)hipFree(g->accum[k]);
         if (k < g->streams.size() && g->streams[k]) (void)hipStreamDestroy(g->streams[k]);
-        if (k < g->scenes.size() && g->scenes[k]) (void)rt_scene_destroy(g->scenes[k]);
+        if (k < g->scenes.size() && g->scenes[k]) (void)P::destroy(g->scenes[k]);
     }
     if (g->stage) { (void)hipSetDevice(g->devices[0]); (void)hipFree(g->stage); }
     delete g;
     return RT_OK;
 }
 
-int rt_group_create(const rtSceneDesc* desc, const int* devices, int n_devices, rtGroup** out) {
+template <class P>
+int group_create(const typename P::Desc* desc, const int* devices, int n_devices, Group<P>** out) {
     if (!desc || !out) return rt_fail(RT_EINVAL, "rt_group_create: null argument");
     *out = nullptr;
     if (n_devices < 0 || (n_devices > 0 && !devices)) return rt_fail(RT_EINVAL, "rt_group_create: bad device list");
     int visible = 0;
     hipError_t e = hipGetDeviceCount(&visible);
     if (e != hipSuccess || visible == 0) return rt_fail(RT_ENODEV, "no HIP device available (%s)", hipGetErrorString(e));
-    rtGroup* g = new (std::nothrow) rtGroup();
+    Group<P>* g = new (std::nothrow) Group<P>();
     if (!g) return rt_fail(RT_ENOMEM, "out of host memory");
     if (n_devices == 0) for (int d = 0; d < visible; ++d) g->devices.push_back(d);
     else g->devices.assign(devices, devices + n_devices);
@@ -128,12 +162,12 @@ int rt_group_create(const rtSceneDesc* desc, const int* devices, int n_devices, 
     g->accum.assign(G, nullptr);
     g->accum_cap.assign(G, 0);
     for (size_t k = 0; k < G; ++k) {
-        int st = rt_scene_create(desc, g->devices[k], &g->scenes[k]); // (leaves that device current)
+        int st = P::create(desc, g->devices[k], &g->scenes[k]); // (leaves that device current)
         if (st == RT_OK && hipStreamCreateWithFlags(&g->streams[k], hipStreamNonBlocking) != hipSuccess)
             st = rt_fail(RT_EHIP, "hipStreamCreate failed on device %d", g->devices[k]);
         if (st != RT_OK) {
             const std::string msg = rt_last_error();
-            rt_group_destroy(g);
+            group_destroy(g);
             return rt_fail(st, "%s", msg.c_str());
         }
     }
@@ -141,25 +175,21 @@ int rt_group_create(const rtSceneDesc* desc, const int* devices, int n_devices, 
     return RT_OK;
 }
 
-int rt_group_size(const rtGroup* g, int* n_devices) {
-    if (!g || !n_devices) return rt_fail(RT_EINVAL, "rt_group_size: null argument");
-    *n_devices = (int)g->devices.size();
-    return RT_OK;
-}
-
-int rt_group_render(rtGroup* g, const rtCamera* camera, const float* pattern, int n, const float background[3], int width,
-                    int height, int max_depth, uint64_t seed, uint32_t flags, float* out, rtStats* stats) {
-    if (!g || !camera || !pattern || !background || !out) return rt_fail(RT_EINVAL, "rt_group_render: null argument");
+template <class P>
+int group_render(Group<P>* g, const typename P::Camera* camera, const typename P::real* pattern, int n, const typename P::real* background,
+                 int width, int height, int max_depth, uint64_t seed, uint32_t flags, typename P::real* out, rtStats* stats) {
+    typedef typename P::real real;
+    if (!g || !camera || !pattern || !background || !out) return rt_fail(RT_EINVAL, "%s: null argument", P::name());
     if (width < 2 || height < 2) return rt_fail(RT_EINVAL, "width and height must be at least 2");
     if ((uint64_t)width * (uint64_t)height > 0x7FFFFFFFull / 3ull) return rt_fail(RT_EINVAL, "image too large");
-    if (flags & RT_FLAG_COUNTERS) return rt_fail(RT_EINVAL, "rt_group_render: RT_FLAG_COUNTERS is per scene (use rt_render)");
+    if (flags & RT_FLAG_COUNTERS) return rt_fail(RT_EINVAL, "%s: RT_FLAG_COUNTERS is per scene (use rt_render)", P::name());
     const size_t G = g->devices.size();
     const size_t image_floats = (size_t)3 * (size_t)width * (size_t)height;
     for (size_t k = 0; k < G; ++k) {
         if (g->accum_cap[k] >= image_floats) continue;
         GROUP_HIP(hipSetDevice(g->devices[k]));
         if (g->accum[k]) { GROUP_HIP(hipFree(g->accum[k])); g->accum[k] = nullptr; g->accum_cap[k] = 0; }
-        GROUP_HIP(hipMalloc((void**)&g->accum[k], image_floats * sizeof(float)));
+        GROUP_HIP(hipMalloc((void**)&g->accum[k], image_floats * sizeof(real)));
         g->accum_cap[k] = image_floats;
     }
     GROUP_HIP(hipSetDevice(g->devices[0]));
@@ -175,8 +205,8 @@ int rt_group_render(rtGroup* g, const rtCamera* camera, const float* pattern, in
     std::vector<int> status(G, RT_OK);
     std::vector<std::string> message(G);
     auto work = [&](size_t k) {
-        int st = rt_render_accumulate(g->scenes[k], camera, pattern, n, (int)k, (int)G, background, width, height, max_depth, seed,
-                                      flags & ~RT_FLAG_TIMING, g->accum[k], g->streams[k]);
+        int st = P::accumulate(g->scenes[k], camera, pattern, n, (int)k, (int)G, background, width, height, max_depth, seed, flags, g->accum[k],
+                               g->streams[k]);
         if (st == RT_OK && hipStreamSynchronize(g->streams[k]) != hipSuccess) st = rt_fail(RT_EHIP, "hipStreamSynchronize failed");
         status[k] = st;
         if (st != RT_OK) message[k] = rt_last_error(); // (the message lives in this thread)
@@ -197,12 +227,12 @@ int rt_group_render(rtGroup* g, const rtCamera* camera, const float* pattern, in
         GROUP_HIP(hipSetDevice(g->devices[0]));
         if (g->stage_cap < image_floats) {
             if (g->stage) { GROUP_HIP(hipFree(g->stage)); g->stage = nullptr; g->stage_cap = 0; }
-            GROUP_HIP(hipMalloc((void**)&g->stage, image_floats * sizeof(float)));
+            GROUP_HIP(hipMalloc((void**)&g->stage, image_floats * sizeof(real)));
             g->stage_cap = image_floats;
         }
         for (size_t k = 1; k < G; ++k) {
-            GROUP_HIP(hipMemcpyPeerAsync(g->stage, g->devices[0], g->accum[k], g->devices[k], image_floats * sizeof(float), g->streams[0]));
-            rt_launch_add(g->accum[0], g->stage, image_floats, g->streams[0]);
+            GROUP_HIP(hipMemcpyPeerAsync(g->stage, g->devices[0], g->accum[k], g->devices[k], image_floats * sizeof(real), g->streams[0]));
+            P::add(g->accum[0], g->stage, image_floats, g->streams[0]);
             GROUP_HIP(hipGetLastError());
         }
     } else if (G > 1 || std::getenv("RT_AMD_FORCE_RCCL")) {
@@ -217,7 +247,7 @@ int rt_group_render(rtGroup* g, const rtCamera* camera, const float* pattern, in
         hipError_t he = hipSuccess;
         for (size_t k = 0; k < G && r == ncclSuccess && he == hipSuccess; ++k) {
             he = hipSetDevice(g->devices[k]);
-            if (he == hipSuccess) r = R->Reduce(g->accum[k], g->accum[k], image_floats, ncclFloat, ncclSum, 0, g->comms[k], g->streams[k]);
+            if (he == hipSuccess) r = R->Reduce(g->accum[k], g->accum[k], image_floats, P::nccl_type(), ncclSum, 0, g->comms[k], g->streams[k]);
         }
         ncclResult_t r2 = R->GroupEnd(); // (always closed, whatever happened inside)
         if (r == ncclSuccess) r = r2;
@@ -226,10 +256,10 @@ int rt_group_render(rtGroup* g, const rtCamera* camera, const float* pattern, in
         for (size_t k = 1; k < G; ++k) { GROUP_HIP(hipSetDevice(g->devices[k])); GROUP_HIP(hipStreamSynchronize(g->streams[k])); }
     }
     GROUP_HIP(hipSetDevice(g->devices[0]));
-    int st = rt_finalize(g->scenes[0], g->accum[0], n, width, height, g->accum[0], g->streams[0]);
+    int st = P::finalize(g->scenes[0], g->accum[0], n, width, height, g->accum[0], g->streams[0]);
     if (st != RT_OK) return st;
     GROUP_HIP(hipEventRecord(e1, g->streams[0]));
-    GROUP_HIP(hipMemcpyAsync(out, g->accum[0], image_floats * sizeof(float), hipMemcpyDeviceToHost, g->streams[0]));
+    GROUP_HIP(hipMemcpyAsync(out, g->accum[0], image_floats * sizeof(real), hipMemcpyDeviceToHost, g->streams[0]));
     GROUP_HIP(hipStreamSynchronize(g->streams[0]));
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
@@ -239,6 +269,48 @@ int rt_group_render(rtGroup* g, const rtCamera* camera, const float* pattern, in
         stats->paths = (uint64_t)width * (uint64_t)height * (uint64_t)n;
     }
     return RT_OK;
+}
+
+} // namespace
+
+struct rtGroup : Group<Float32Path> {};
+struct rtGroup64 : Group<Float64Path> {};
+
+extern "C" {
+
+int rt_group_destroy(rtGroup* g) { return group_destroy<Float32Path>(g); }
+int rt_group_create(const rtSceneDesc* desc, const int* devices, int n_devices, rtGroup** out) {
+    Group<Float32Path>* g = nullptr;
+    int st = group_create<Float32Path>(desc, devices, n_devices, &g);
+    if (out) *out = static_cast<rtGroup*>(g);
+    return st;
+}
+int rt_group_size(const rtGroup* g, int* n_devices) {
+    if (!g || !n_devices) return rt_fail(RT_EINVAL, "rt_group_size: null argument");
+    *n_devices = (int)g->devices.size();
+    return RT_OK;
+}
+int rt_group_render(rtGroup* g, const rtCamera* camera, const float* pattern, int n, const float background[3], int width,
+                    int height, int max_depth, uint64_t seed, uint32_t flags, float* out, rtStats* stats) {
+    return group_render<Float32Path>(g, camera, pattern, n, background, width, height, max_depth, seed, flags, out, stats);
+}
+
+// the same for render(Float64, ...): the members are Float64 scenes, the accumulators doubles (ncclDouble)
+int rt_group_destroy_f64(rtGroup64* g) { return group_destroy<Float64Path>(g); }
+int rt_group_create_f64(const rtSceneDesc64* desc, const int* devices, int n_devices, rtGroup64** out) {
+    Group<Float64Path>* g = nullptr;
+    int st = group_create<Float64Path>(desc, devices, n_devices, &g);
+    if (out) *out = static_cast<rtGroup64*>(g);
+    return st;
+}
+int rt_group_size_f64(const rtGroup64* g, int* n_devices) {
+    if (!g || !n_devices) return rt_fail(RT_EINVAL, "rt_group_size_f64: null argument");
+    *n_devices = (int)g->devices.size();
+    return RT_OK;
+}
+int rt_group_render_f64(rtGroup64* g, const rtCamera64* camera, const double* pattern, int n, const double background[3], int width,
+                        int height, int max_depth, uint64_t seed, uint32_t flags, double* out, rtStats* stats) {
+    return group_render<Float64Path>(g, camera, pattern, n, background, width, height, max_depth, seed, flags, out, stats);
 }
 
 } // extern "C"

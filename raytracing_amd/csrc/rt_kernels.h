@@ -78,6 +78,7 @@ void rt_launch_redo(const DevScene* S, const RtRenderParams* P, const PathPool* 
 void rt_launch_compact(const PathPool* from, float4* to, uint32_t* d_counts, uint32_t* d_sync, hipStream_t stream);
 void rt_launch_sum(const RtRenderParams* P, const float4* d_radiance, float* d_accum, int first_batch, hipStream_t stream);
 void rt_launch_add(float* d_dst, const float* d_src, size_t n, hipStream_t stream); // dst[i] += src[i]
+void rt64_launch_add(double* d_dst, const double* d_src, size_t n, hipStream_t stream); // the same in double (rt_f64.hip)
 void rt_launch_finalize(const float* d_accum, float inv_n, size_t image_floats, float* d_out, hipStream_t stream);
 void rt_launch_finalize_rgb8(const float* d_accum, float inv_n, int width, int height, uint8_t* d_out, hipStream_t stream);
 void rt_launch_trace_rays(const DevScene* S, const float* d_rays, int n, float t_min, float t_max, uint32_t seed32,

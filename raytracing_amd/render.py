@@ -268,23 +268,27 @@ class DeviceScene:
 class DeviceGroup:
     """The scene on several GPUs of one host process (rt_group_create): render() deals the pattern columns to them,
     sums their accumulators on the first device (RCCL, or peer copies with RT_AMD_REDUCE=peer) and returns the image.
-    devices: a list of device numbers (a number may appear twice: several shards on one GPU), None = every visible GPU."""
+    devices: a list of device numbers (a number may appear twice: several shards on one GPU), None = every visible GPU.
+    F: the element type, numpy.float32 or numpy.float64 (rt_group_*_f64)."""
 
-    def __init__(self, world, devices=None):
+    def __init__(self, world, devices=None, F=np.float32):
+        self.rec = ffi.records(F)
+        self.F = self.rec.np_type
         self.world = list(world)
-        bvh = build_bvh_scene(SceneManager(self.world))
-        desc, keep = flatten_scene(self.world, bvh)
+        with H.element_type(self.F):
+            bvh = build_bvh_scene(SceneManager(self.world))
+            desc, keep = flatten_scene(self.world, bvh)
         self.handle = C.c_void_p()
         dev = np.ascontiguousarray(devices if devices is not None else [], dtype=np.int32)
-        ffi.check(ffi.lib().rt_group_create(C.byref(desc), ffi.iptr(dev) if len(dev) else None, len(dev), C.byref(self.handle)))
+        ffi.check(self.rec.fn("rt_group_create")(C.byref(desc), ffi.iptr(dev) if len(dev) else None, len(dev), C.byref(self.handle)))
         del keep
         n = C.c_int(0)
-        ffi.check(ffi.lib().rt_group_size(self.handle, C.byref(n)))
+        ffi.check(self.rec.fn("rt_group_size")(self.handle, C.byref(n)))
         self.n_devices = n.value
 
     def close(self):
         if self.handle:
-            ffi.lib().rt_group_destroy(self.handle)
+            self.rec.fn("rt_group_destroy")(self.handle)
             self.handle = C.c_void_p()
 
     def __del__(self):
@@ -295,13 +299,14 @@ class DeviceGroup:
 
     def render(self, camera, pattern, background, width, height, max_depth=50, seed=DEFAULT_SEED, flags=0):
         """Returns (img, stats) like DeviceScene.render."""
-        pat, n = _pattern(pattern)
+        rec, F = self.rec, self.F
+        pat, n = _pattern(pattern, F)
         bg = np.asarray(background, dtype=F)
         out = np.zeros(3 * width * height, dtype=F)
         st = ffi.rtStats()
-        cam = camera_record(camera)
-        ffi.check(ffi.lib().rt_group_render(self.handle, C.byref(cam), ffi.fptr(pat), n, ffi.fptr(bg), width, height,
-                                            max_depth, seed, flags, ffi.fptr(out), C.byref(st)))
+        cam = camera_record(camera, rec)
+        ffi.check(rec.fn("rt_group_render")(self.handle, C.byref(cam), rec.ptr(pat), n, rec.ptr(bg), width, height,
+                                            max_depth, seed, flags, rec.ptr(out), C.byref(st)))
         return out.reshape(width, height, 3).transpose(1, 0, 2).copy(), st
 
 
@@ -340,9 +345,7 @@ def _render(world, material, width, height, camera, background, pattern, gpu, sp
                                   "the MI355X path (gpu=True)")
     # devices: a list of GPUs to spread the samples over (rt_group_*), "all" = every visible GPU; default: the one `device`
     if devices is not None:
-        if F is not np.float32:
-            raise NotImplementedError("rt_group_* (several GPUs in one process) exists for Float32 only")
-        scene = DeviceGroup(world, devices=None if isinstance(devices, str) and devices == "all" else devices)
+        scene = DeviceGroup(world, devices=None if isinstance(devices, str) and devices == "all" else devices, F=F)
     else:
         scene = DeviceScene(world, device=device, F=F)
     try:

@@ -214,6 +214,37 @@ def test_progressive_rendering_and_resume_in_float64(tmp_path):
         dev.close()
 
 
+def test_group_of_float64_scenes(monkeypatch):
+    """rt_group_*_f64: one member renders rt_render_f64's picture bit for bit; two members on the one GPU (peer copies
+    and adds) and one member through the RCCL binding give it up to the order of the sums."""
+    world, kw = rt.get_scene("cornell_smoke_box", spp=6, F=F)
+    cam, pat, bg = kw["camera"], kw["pattern"], kw["background"]
+    W, Hh = 40, 32
+    dev = rt.DeviceScene(world, F=F)
+    want, _ = dev.render(cam, pat, bg, W, Hh)
+    dev.close()
+    one = rt.DeviceGroup(world, devices=[0], F=F)
+    try:
+        assert one.n_devices == 1
+        img, st = one.render(cam, pat, bg, W, Hh)
+        assert img.dtype == F and st.paths == W * Hh * 6
+        np.testing.assert_array_equal(bits(img), bits(want))
+        monkeypatch.setenv("RT_AMD_FORCE_RCCL", "1")
+        img, _ = one.render(cam, pat, bg, W, Hh)
+        monkeypatch.delenv("RT_AMD_FORCE_RCCL")
+        np.testing.assert_array_equal(bits(img), bits(want))
+    finally:
+        one.close()
+    two = rt.DeviceGroup(world, devices=[0, 0], F=F)
+    try:
+        assert two.n_devices == 2
+        img, _ = two.render(cam, pat, bg, W, Hh)
+        np.testing.assert_allclose(img, want, rtol=1e-13, atol=1e-300)
+        assert np.array_equal(rt.render("cornell_smoke_box", gpu=True, spp=6, width=W, height=Hh, devices=[0, 0], F=F), img)
+    finally:
+        two.close()
+
+
 def test_bad_arguments_are_errors():
     from raytracing_amd import _ffi as ffi
     world, kw = rt.get_scene("cornell_box", spp=2, F=F)

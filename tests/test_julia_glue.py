@@ -149,7 +149,8 @@ def test_every_ccall_names_a_declared_entry_point_with_matching_arguments():
                 else:
                     assert kind[p] is a, (fn, p, a)
     assert {"rt_scene_create", "rt_scene_destroy", "rt_render", "rt_group_create", "rt_group_render", "rt_group_destroy",
-            "rt_last_error", "rt_device_count", "rt_scene_create_f64", "rt_scene_destroy_f64", "rt_render_f64"} <= seen
+            "rt_last_error", "rt_device_count", "rt_scene_create_f64", "rt_scene_destroy_f64", "rt_render_f64", "rt_group_create_f64",
+            "rt_group_render_f64", "rt_group_destroy_f64"} <= seen
 
 
 def strip_code(text):
