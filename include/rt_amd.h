@@ -391,6 +391,10 @@ int rt_render_accumulate_f64(rtScene64* scene, const rtCamera64* camera, const d
                              int sample_stride, const double background[3], int width, int height, int max_depth,
                              uint64_t seed, double* d_accum, void* stream);
 int rt_finalize_f64(rtScene64* scene, const double* d_accum, int n_total, int width, int height, double* d_out, void* stream);
+/* the step after the path (README.md:50-67: save(path, clamp01.(img))) for an RGB{Float64} image, as rt_finalize_rgb8 /
+ * rt_image_to_rgb8: N0f8(x::Float64) rounds x * 255 to the nearest even in double.  The bytes go to rt_write_png / _ppm. */
+int rt_finalize_rgb8_f64(rtScene64* scene, const double* d_accum, int n_total, int width, int height, uint8_t* d_rgb8, void* stream);
+int rt_image_to_rgb8_f64(const double* img, int width, int height, uint8_t* rgb8);
 /* parity hooks, as rt_trace_rays / rt_trace_paths */
 int rt_trace_rays_f64(rtScene64* scene, const double* rays, int n, double t_min, double t_max, uint64_t seed,
                       int32_t* prim_id, int32_t* sub_id, double* t, double* normal, double* uv, uint8_t* front);
@@ -406,6 +410,12 @@ int rt_group_render_f64(rtGroup64* group, const rtCamera64* camera, const double
                         int width, int height, int max_depth, uint64_t seed, uint32_t flags, double* out, rtStats* stats);
 int rt_group_destroy_f64(rtGroup64* group);
 /* build_bvh (src/BVH.jl:65-109, src/mesh.jl:217-305) over Float64 boxes and vertices, as rt_bvh_build / rt_bvh_build_meshes */
+/* scene descriptions in a file, as rt_scene_desc_save / _load / _free; the file carries its element type and each loader
+ * refuses the other's files (RT_EINVAL) */
+int rt_scene_desc_save_f64(const rtSceneDesc64* desc, const char* path);
+int rt_scene_desc_load_f64(const char* path, rtSceneDesc64** out);
+void rt_scene_desc_free_f64(rtSceneDesc64* desc);
+
 int rt_bvh_build_f64(int n, const double* object_bounds, int32_t* order, double* node_bounds, int32_t* node_left,
                      int32_t* node_right, uint8_t* node_leaf);
 int rt_bvh_build_meshes_f64(int n_meshes, const int32_t* n_vertices, const double* const* vertices,

@@ -209,6 +209,8 @@ SYMBOLS = {
                                  C.c_uint64, c_i32p, C.c_int, c_f32p]),
     "rt_finalize_rgb8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rt_image_to_rgb8": (C.c_int, [c_f32p, C.c_int, C.c_int, c_u8p]),
+    "rt_finalize_rgb8_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "rt_image_to_rgb8_f64": (C.c_int, [c_f64p, C.c_int, C.c_int, c_u8p]),
     "rt_write_png": (C.c_int, [C.c_char_p, c_u8p, C.c_int, C.c_int]),
     "rt_write_ppm": (C.c_int, [C.c_char_p, c_u8p, C.c_int, C.c_int]),
     "rt_obj_load": (C.c_int, [C.c_char_p, C.POINTER(rtObjMesh)]),
@@ -216,6 +218,9 @@ SYMBOLS = {
     "rt_scene_desc_save": (C.c_int, [C.POINTER(rtSceneDesc), C.c_char_p]),
     "rt_scene_desc_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(rtSceneDesc))]),
     "rt_scene_desc_free": (None, [C.POINTER(rtSceneDesc)]),
+    "rt_scene_desc_save_f64": (C.c_int, [C.POINTER(rtSceneDesc64), C.c_char_p]),
+    "rt_scene_desc_load_f64": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(rtSceneDesc64))]),
+    "rt_scene_desc_free_f64": (None, [C.POINTER(rtSceneDesc64)]),
     "rt_perlin_generate": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint64), C.c_int32, C.POINTER(rtPerlin)]),
     "rt_scene_nodes": (C.c_int, [C.c_void_p, C.POINTER(rtLayout), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_int32),
                                  C.c_size_t, C.POINTER(rtBuildInfo)]),

@@ -1595,6 +1595,31 @@ extern "C" int rt_finalize_f64(rtScene64* s, const double* d_accum, int n_total,
     return RT_OK;
 }
 
+// rt64_finalize_kernel + clamp01nan + N0f8 (round to nearest even of x * 255, in double); out is H x W x 3 bytes, row 0 = top
+__global__ void __launch_bounds__(256) rt64_finalize_rgb8_kernel(const real* __restrict__ accum, real inv_n, int width, int height,
+                                                                 uint8_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)width * (size_t)height) return;
+    int y = (int)(i / (size_t)width), x = (int)(i - (size_t)y * (size_t)width);
+    const real* a = accum + ((size_t)x * (size_t)height + (size_t)y) * 3u;
+    for (int c = 0; c < 3; ++c) {
+        real v = __builtin_sqrt(a[c] * inv_n);
+        if (!(v == v)) v = 0.0;
+        v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+        out[i * 3u + (size_t)c] = (uint8_t)__builtin_rint(v * 255.0);
+    }
+}
+
+extern "C" int rt_finalize_rgb8_f64(rtScene64* s, const double* d_accum, int n_total, int width, int height, uint8_t* d_rgb8, void* stream) {
+    if (!s || !d_accum || !d_rgb8 || n_total <= 0 || width <= 0 || height <= 0) return rt_fail(RT_EINVAL, "rt_finalize_rgb8_f64: bad argument");
+    HIP_TRY64(hipSetDevice(s->device));
+    size_t pixels = (size_t)width * (size_t)height;
+    real inv_n = (real)(1.0 / (double)n_total);
+    hipLaunchKernelGGL(rt64_finalize_rgb8_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_accum, inv_n, width, height, d_rgb8);
+    HIP_TRY64(hipGetLastError());
+    return RT_OK;
+}
+
 extern "C" int rt_render_f64(rtScene64* s, const rtCamera64* camera, const double* pattern, int n, const double background[3], int width, int height,
                              int max_depth, uint64_t seed, uint32_t flags, double* out, rtStats* stats) {
     (void)flags;

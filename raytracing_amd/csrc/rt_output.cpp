@@ -18,6 +18,12 @@ inline uint8_t quantise(float x) {
     return (uint8_t)std::nearbyintf(x * 255.0f);
 }
 
+inline uint8_t quantise(double x) { // N0f8(x::Float64): the product and the rounding in double
+    if (!(x == x)) x = 0.0;
+    x = x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x);
+    return (uint8_t)std::nearbyint(x * 255.0);
+}
+
 void put32(std::vector<uint8_t>& v, uint32_t x) {
     v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
 }
@@ -35,6 +41,16 @@ void chunk(std::vector<uint8_t>& out, const char type[4], const uint8_t* data, s
 int rt_image_to_rgb8(const float* img, int width, int height, uint8_t* rgb8) {
     if (!img || !rgb8) return rt_fail(RT_EINVAL, "rt_image_to_rgb8: null argument");
     if (width < 1 || height < 1) return rt_fail(RT_EINVAL, "rt_image_to_rgb8: bad size");
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x)
+            for (int c = 0; c < 3; ++c)
+                rgb8[((size_t)y * width + x) * 3 + c] = quantise(img[((size_t)x * height + y) * 3 + c]);
+    return RT_OK;
+}
+
+int rt_image_to_rgb8_f64(const double* img, int width, int height, uint8_t* rgb8) {
+    if (!img || !rgb8) return rt_fail(RT_EINVAL, "rt_image_to_rgb8_f64: null argument");
+    if (width < 1 || height < 1) return rt_fail(RT_EINVAL, "rt_image_to_rgb8_f64: bad size");
     for (int y = 0; y < height; ++y)
         for (int x = 0; x < width; ++x)
             for (int c = 0; c < 3; ++c)

@@ -5,7 +5,8 @@
 //
 // File: "RTSCENE1", then the ten tables in the order of the struct, each as a 64-bit element count followed by the
 // elements; variable-length members (image texels, mesh arrays, tree arrays) follow their record as counted arrays.
-// Little-endian, 4-byte floats, as in memory.
+// Little-endian, 4-byte floats, as in memory.  A Float64 description (rtSceneDesc64) is written the same way under the
+// tag "RTSCEN64" with 8-byte floats; each loader refuses the other's files.
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -18,7 +19,20 @@
 
 namespace {
 
-const char MAGIC[8] = {'R', 'T', 'S', 'C', 'E', 'N', 'E', '1'};
+// the record types of one element type
+struct Float32Records {
+    typedef rtSceneDesc Desc; typedef rtObject Object; typedef rtTransform Transform; typedef rtMaterial Material;
+    typedef rtTexture Texture; typedef rtPerlin Perlin; typedef rtMesh Mesh; typedef rtBvh Bvh; typedef float real;
+    static const char* magic() { return "RTSCENE1"; }
+    static const char* suffix() { return ""; }
+};
+struct Float64Records {
+    typedef rtSceneDesc64 Desc; typedef rtObject64 Object; typedef rtTransform64 Transform; typedef rtMaterial64 Material;
+    typedef rtTexture64 Texture; typedef rtPerlin64 Perlin; typedef rtMesh64 Mesh; typedef rtBvh64 Bvh; typedef double real;
+    static const char* magic() { return "RTSCEN64"; }
+    static const char* suffix() { return "_f64"; }
+};
+const size_t MAGIC_BYTES = 8;
 
 struct Writer {
     FILE* f;
@@ -29,7 +43,7 @@ struct Writer {
         count(p ? n : 0);
         if (p) raw(p, n * sizeof(T));
     }
-    void tree(const rtBvh& t) {
+    template <typename Bvh> void tree(const Bvh& t) {
         int32_t head[2] = {t.kind, t.n_nodes};
         raw(head, sizeof(head));
         array(t.objects, (size_t)(t.n_objects > 0 ? t.n_objects : 0));
@@ -42,25 +56,25 @@ struct Writer {
 };
 
 // everything the pointers of a loaded description point into
-struct Loaded {
-    std::vector<rtObject> objects;
+template <class R> struct Loaded {
+    std::vector<typename R::Object> objects;
     std::vector<int32_t> top;
-    std::vector<rtTransform> transforms;
-    std::vector<rtMaterial> materials;
-    std::vector<rtTexture> textures;
+    std::vector<typename R::Transform> transforms;
+    std::vector<typename R::Material> materials;
+    std::vector<typename R::Texture> textures;
     std::vector<rtImage> images;
-    std::vector<rtPerlin> perlins;
-    std::vector<rtMesh> meshes;
-    std::vector<rtBvh> groups, buckets;
-    std::vector<std::vector<uint8_t>> bytes;   // image texels, leaf flags
-    std::vector<std::vector<int32_t>> ints;    // mesh indices / materials / ids, tree arrays
-    std::vector<std::vector<float>> floats;    // mesh vertices, tree bounds
+    std::vector<typename R::Perlin> perlins;
+    std::vector<typename R::Mesh> meshes;
+    std::vector<typename R::Bvh> groups, buckets;
+    std::vector<std::vector<uint8_t>> bytes;            // image texels, leaf flags
+    std::vector<std::vector<int32_t>> ints;             // mesh indices / materials / ids, tree arrays
+    std::vector<std::vector<typename R::real>> reals;   // mesh vertices, tree bounds
 };
 
-// what rt_scene_desc_load hands out: the description first (plain data, so a pointer to it is a pointer to the handle)
-struct Handle {
-    rtSceneDesc desc;
-    Loaded* tables;
+// what the loader hands out: the description first (plain data, so a pointer to it is a pointer to the handle)
+template <class R> struct Handle {
+    typename R::Desc desc;
+    Loaded<R>* tables;
 };
 
 struct Reader {
@@ -93,7 +107,7 @@ struct Reader {
         store.push_back(std::move(v));
         return store.back().data();
     }
-    bool tree(Loaded& L, rtBvh& t) {
+    template <class R> bool tree(Loaded<R>& L, typename R::Bvh& t) {
         int32_t head[2];
         if (!raw(head, sizeof(head))) return false;
         std::memset(&t, 0, sizeof(t));
@@ -101,7 +115,7 @@ struct Reader {
         t.n_nodes = head[1];
         uint64_t n_obj = 0, nb = 0, nl = 0, nr = 0, nf = 0;
         t.objects = array(L.ints, &n_obj);
-        t.node_bounds = array(L.floats, &nb);
+        t.node_bounds = array(L.reals, &nb);
         t.node_left = array(L.ints, &nl);
         t.node_right = array(L.ints, &nr);
         t.node_leaf = array(L.bytes, &nf);
@@ -112,19 +126,15 @@ struct Reader {
     }
 };
 
-} // namespace
-
-extern "C" {
-
-int rt_scene_desc_save(const rtSceneDesc* d, const char* path) {
-    if (!d || !path) return rt_fail(RT_EINVAL, "rt_scene_desc_save: null argument");
+template <class R> int desc_save(const typename R::Desc* d, const char* path) {
+    if (!d || !path) return rt_fail(RT_EINVAL, "rt_scene_desc_save%s: null argument", R::suffix());
     if (d->n_objects < 0 || d->n_top < 0 || d->n_transforms < 0 || d->n_materials < 0 || d->n_textures < 0 || d->n_images < 0 ||
         d->n_perlins < 0 || d->n_meshes < 0 || d->n_groups < 0 || d->n_buckets < 0)
-        return rt_fail(RT_EINVAL, "rt_scene_desc_save: negative count");
+        return rt_fail(RT_EINVAL, "rt_scene_desc_save%s: negative count", R::suffix());
     FILE* f = std::fopen(path, "wb");
-    if (!f) return rt_fail(RT_EINVAL, "rt_scene_desc_save: cannot open %s for writing", path);
+    if (!f) return rt_fail(RT_EINVAL, "rt_scene_desc_save%s: cannot open %s for writing", R::suffix(), path);
     Writer w{f};
-    w.raw(MAGIC, sizeof(MAGIC));
+    w.raw(R::magic(), MAGIC_BYTES);
     w.array(d->objects, (size_t)d->n_objects);
     w.array(d->top, (size_t)d->n_top);
     w.array(d->transforms, (size_t)d->n_transforms);
@@ -140,7 +150,7 @@ int rt_scene_desc_save(const rtSceneDesc* d, const char* path) {
     w.array(d->perlins, (size_t)d->n_perlins);
     w.count((uint64_t)d->n_meshes);
     for (int i = 0; i < d->n_meshes; ++i) {
-        const rtMesh& m = d->meshes[i];
+        const typename R::Mesh& m = d->meshes[i];
         w.array(m.vertices, (size_t)8 * (size_t)(m.n_vertices > 0 ? m.n_vertices : 0));
         w.array(m.indices, (size_t)4 * (size_t)(m.n_triangles > 0 ? m.n_triangles : 0));
         w.array(m.materials, (size_t)(m.n_materials > 0 ? m.n_materials : 0));
@@ -151,25 +161,25 @@ int rt_scene_desc_save(const rtSceneDesc* d, const char* path) {
     w.count((uint64_t)d->n_buckets);
     for (int i = 0; i < d->n_buckets; ++i) w.tree(d->buckets[i]);
     const bool closed = std::fclose(f) == 0;
-    if (!w.ok || !closed) return rt_fail(RT_EINVAL, "rt_scene_desc_save: write to %s failed", path);
+    if (!w.ok || !closed) return rt_fail(RT_EINVAL, "rt_scene_desc_save%s: write to %s failed", R::suffix(), path);
     return RT_OK;
 }
 
-int rt_scene_desc_load(const char* path, rtSceneDesc** out) {
-    if (!path || !out) return rt_fail(RT_EINVAL, "rt_scene_desc_load: null argument");
+template <class R> int desc_load(const char* path, typename R::Desc** out) {
+    if (!path || !out) return rt_fail(RT_EINVAL, "rt_scene_desc_load%s: null argument", R::suffix());
     *out = nullptr;
     FILE* f = std::fopen(path, "rb");
-    if (!f) return rt_fail(RT_EINVAL, "rt_scene_desc_load: cannot open %s", path);
+    if (!f) return rt_fail(RT_EINVAL, "rt_scene_desc_load%s: cannot open %s", R::suffix(), path);
     std::vector<uint8_t> buf;
     uint8_t chunk[1 << 16];
     size_t got;
     while ((got = std::fread(chunk, 1, sizeof(chunk), f)) > 0) buf.insert(buf.end(), chunk, chunk + got);
     std::fclose(f);
-    if (buf.size() < sizeof(MAGIC) || std::memcmp(buf.data(), MAGIC, sizeof(MAGIC)) != 0)
-        return rt_fail(RT_EINVAL, "rt_scene_desc_load: %s is not a scene file", path);
-    Loaded* L = new (std::nothrow) Loaded();
+    if (buf.size() < MAGIC_BYTES || std::memcmp(buf.data(), R::magic(), MAGIC_BYTES) != 0)
+        return rt_fail(RT_EINVAL, "rt_scene_desc_load%s: %s is not a scene file of this element type", R::suffix(), path);
+    Loaded<R>* L = new (std::nothrow) Loaded<R>();
     if (!L) return rt_fail(RT_ENOMEM, "out of host memory");
-    Reader r{buf.data() + sizeof(MAGIC), buf.size() - sizeof(MAGIC)};
+    Reader r{buf.data() + MAGIC_BYTES, buf.size() - MAGIC_BYTES};
     r.table(L->objects);
     r.table(L->top);
     r.table(L->transforms);
@@ -189,10 +199,10 @@ int rt_scene_desc_load(const char* path, rtSceneDesc** out) {
     r.table(L->perlins);
     n = r.count(32);
     for (uint64_t i = 0; r.ok && i < n; ++i) {
-        rtMesh m;
+        typename R::Mesh m;
         std::memset(&m, 0, sizeof(m));
         uint64_t nv = 0, ni = 0, nm = 0, nt = 0;
-        m.vertices = r.array(L->floats, &nv);
+        m.vertices = r.array(L->reals, &nv);
         m.indices = r.array(L->ints, &ni);
         m.materials = r.array(L->ints, &nm);
         m.tri_ids = r.array(L->ints, &nt);
@@ -201,17 +211,17 @@ int rt_scene_desc_load(const char* path, rtSceneDesc** out) {
         L->meshes.push_back(m);
     }
     n = r.count(8);
-    for (uint64_t i = 0; r.ok && i < n; ++i) { rtBvh t; if (r.tree(*L, t)) L->groups.push_back(t); }
+    for (uint64_t i = 0; r.ok && i < n; ++i) { typename R::Bvh t; if (r.tree<R>(*L, t)) L->groups.push_back(t); }
     n = r.count(8);
-    for (uint64_t i = 0; r.ok && i < n; ++i) { rtBvh t; if (r.tree(*L, t)) L->buckets.push_back(t); }
+    for (uint64_t i = 0; r.ok && i < n; ++i) { typename R::Bvh t; if (r.tree<R>(*L, t)) L->buckets.push_back(t); }
     if (!r.ok || r.left != 0) {
         delete L;
-        return rt_fail(RT_EINVAL, "rt_scene_desc_load: %s is truncated or damaged", path);
+        return rt_fail(RT_EINVAL, "rt_scene_desc_load%s: %s is truncated or damaged", R::suffix(), path);
     }
-    Handle* h = new (std::nothrow) Handle();
+    Handle<R>* h = new (std::nothrow) Handle<R>();
     if (!h) { delete L; return rt_fail(RT_ENOMEM, "out of host memory"); }
     h->tables = L;
-    rtSceneDesc& d = h->desc;
+    typename R::Desc& d = h->desc;
     std::memset(&d, 0, sizeof(d));
     d.n_objects = (int32_t)L->objects.size();       d.objects = L->objects.data();
     d.n_top = (int32_t)L->top.size();               d.top = L->top.data();
@@ -227,11 +237,23 @@ int rt_scene_desc_load(const char* path, rtSceneDesc** out) {
     return RT_OK;
 }
 
-void rt_scene_desc_free(rtSceneDesc* d) {
+template <class R> void desc_free(typename R::Desc* d) {
     if (!d) return;
-    Handle* h = reinterpret_cast<Handle*>(d); // the description is the first member of the handle
+    Handle<R>* h = reinterpret_cast<Handle<R>*>(d); // the description is the first member of the handle
     delete h->tables;
     delete h;
 }
+
+} // namespace
+
+extern "C" {
+
+int rt_scene_desc_save(const rtSceneDesc* d, const char* path) { return desc_save<Float32Records>(d, path); }
+int rt_scene_desc_load(const char* path, rtSceneDesc** out) { return desc_load<Float32Records>(path, out); }
+void rt_scene_desc_free(rtSceneDesc* d) { desc_free<Float32Records>(d); }
+
+int rt_scene_desc_save_f64(const rtSceneDesc64* d, const char* path) { return desc_save<Float64Records>(d, path); }
+int rt_scene_desc_load_f64(const char* path, rtSceneDesc64** out) { return desc_load<Float64Records>(path, out); }
+void rt_scene_desc_free_f64(rtSceneDesc64* d) { desc_free<Float64Records>(d); }
 
 } // extern "C"

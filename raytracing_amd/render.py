@@ -31,13 +31,16 @@ def _pattern(pattern, dtype=F):
     return np.ascontiguousarray(p.T).reshape(-1), p.shape[1]
 
 
-def save_scene(path, world):
+def save_scene(path, world, F=np.float32):
     """Writes the scene description of `world` (its tables and the trees build_bvh makes of it: what rt_scene_create
-    takes) to one binary file (rt_scene_desc_save); DeviceScene.from_file(path) renders it without the world list."""
+    takes) to one binary file (rt_scene_desc_save; F=numpy.float64: the Float64 description, rt_scene_desc_save_f64);
+    DeviceScene.from_file(path) renders it without the world list."""
+    rec = ffi.records(F)
     world = list(world)
-    bvh = build_bvh_scene(SceneManager(world))
-    desc, keep = flatten_scene(world, bvh)
-    ffi.check(ffi.lib().rt_scene_desc_save(C.byref(desc), os.fsencode(path)))
+    with H.element_type(rec.np_type):
+        bvh = build_bvh_scene(SceneManager(world))
+        desc, keep = flatten_scene(world, bvh)
+    ffi.check(rec.fn("rt_scene_desc_save")(C.byref(desc), os.fsencode(path)))
     del keep
 
 
@@ -126,19 +129,20 @@ class DeviceScene:
         return pairs, bool(used.value)
 
     @classmethod
-    def from_file(cls, path, device=0):
-        """A scene written by save_scene (rt_scene_desc_load + rt_scene_create): no world list, no tree build."""
+    def from_file(cls, path, device=0, F=np.float32):
+        """A scene written by save_scene (rt_scene_desc_load + rt_scene_create, or their _f64 forms for a file written
+        with F=numpy.float64): no world list, no tree build.  A file of the other element type is an error."""
         self = cls.__new__(cls)
         self.world = self.scene_manager = self.bvh = self._keep = None
-        self.rec, self.F = ffi.R32, np.float32
+        self.rec = rec = ffi.records(F)
+        self.F = rec.np_type
         self.handle = C.c_void_p()
-        desc = C.POINTER(ffi.rtSceneDesc)()
-        L = ffi.lib()
-        ffi.check(L.rt_scene_desc_load(os.fsencode(path), C.byref(desc)))
+        desc = C.POINTER(rec.rtSceneDesc)()
+        ffi.check(rec.fn("rt_scene_desc_load")(os.fsencode(path), C.byref(desc)))
         try:
-            ffi.check(L.rt_scene_create(desc, int(device), C.byref(self.handle)))
+            ffi.check(rec.fn("rt_scene_create")(desc, int(device), C.byref(self.handle)))
         finally:
-            L.rt_scene_desc_free(desc)
+            rec.fn("rt_scene_desc_free")(desc)
         return self
 
     def close(self):
@@ -195,8 +199,7 @@ class DeviceScene:
 
     def finalize_rgb8(self, d_accum, n_total, width, height, d_rgb8, stream=None):
         """rt_finalize + clamp01 + 8-bit quantisation on the device; d_rgb8 receives height x width x 3 bytes."""
-        self._f32_only("finalize_rgb8()")
-        ffi.check(ffi.lib().rt_finalize_rgb8(self.handle, C.c_void_p(d_accum), n_total, width, height,
+        ffi.check(self.rec.fn("rt_finalize_rgb8")(self.handle, C.c_void_p(d_accum), n_total, width, height,
                                              C.c_void_p(d_rgb8), C.c_void_p(stream or 0)))
 
     def render_progressive(self, camera, pattern, background, width, height, passes=8, state=None, max_depth=50,
@@ -358,16 +361,18 @@ def _render(world, material, width, height, camera, background, pattern, gpu, sp
 
 def clamp01(img):
     """clamp01.(img) with NaN -> 0 (clamp01nan), as the reference's README asks before saving (README.md:56-63)"""
-    a = np.asarray(img, dtype=F)
-    return np.clip(np.where(np.isnan(a), F(0), a), F(0), F(1))
+    T = np.float64 if np.asarray(img).dtype == np.float64 else F
+    a = np.asarray(img, dtype=T)
+    return np.clip(np.where(np.isnan(a), T(0), a), T(0), T(1))
 
 
 def to_rgb8(img):
     """(height, width, 3) float image -> uint8 the way Images.jl stores N0f8: round-to-nearest-even of clamp01(x) * 255"""
-    a = np.ascontiguousarray(np.asarray(img, dtype=F).transpose(1, 0, 2))  # rt_render's memory order [col][row][rgb]
-    h, w = img.shape[0], img.shape[1]
+    rec = ffi.records(np.float64 if np.asarray(img).dtype == np.float64 else F)  # an RGB{Float64} image is quantised in double
+    a = np.ascontiguousarray(np.asarray(img, dtype=rec.np_type).transpose(1, 0, 2))  # rt_render's memory order [col][row][rgb]
+    h, w = a.shape[1], a.shape[0]
     out = np.zeros((h, w, 3), dtype=np.uint8)
-    ffi.check(ffi.lib().rt_image_to_rgb8(ffi.fptr(a), w, h, ffi.bptr(out)))
+    ffi.check(rec.fn("rt_image_to_rgb8")(rec.ptr(a), w, h, ffi.bptr(out)))
     return out
 
 

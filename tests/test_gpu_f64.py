@@ -10,6 +10,7 @@ import pytest
 
 import oracle_ffi as O
 import raytracing_amd as rt
+from raytracing_amd import _ffi as ffi
 from raytracing_amd import hittables as H
 
 pytestmark = pytest.mark.gpu
@@ -212,6 +213,56 @@ def test_progressive_rendering_and_resume_in_float64(tmp_path):
         np.testing.assert_array_equal(bits(rest[-1][1]), bits(steps[-1][1]))
     finally:
         dev.close()
+
+
+def test_device_output_stage_matches_host_quantisation():
+    """rt_finalize_rgb8_f64 (clamp01 + N0f8 in double on the device) == rt_finalize_f64 followed by the host's"""
+    import torch
+    world, kw = rt.get_scene("cornell_box", spp=6, F=F)                # its light (15) is far outside [0, 1]
+    cam, pat, bg = kw["camera"], kw["pattern"], kw["background"]
+    W, Hh = 50, 38
+    dev = rt.DeviceScene(world, F=F)
+    try:
+        stream = torch.cuda.current_stream().cuda_stream
+        acc = torch.zeros(3 * W * Hh, dtype=torch.float64, device="cuda")
+        dev.accumulate(cam, pat, bg, W, Hh, acc.data_ptr(), stream=stream)
+        out = torch.zeros_like(acc)
+        rgb = torch.zeros(Hh * W * 3, dtype=torch.uint8, device="cuda")
+        dev.finalize(acc.data_ptr(), 6, W, Hh, out.data_ptr(), stream=stream)
+        dev.finalize_rgb8(acc.data_ptr(), 6, W, Hh, rgb.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+    finally:
+        dev.close()
+    img = out.cpu().numpy().reshape(W, Hh, 3).transpose(1, 0, 2)
+    got = rgb.cpu().numpy().reshape(Hh, W, 3)
+    assert img.dtype == F
+    np.testing.assert_array_equal(got, rt.to_rgb8(img))
+    assert got.max() == 255 and img.max() > 1.0
+
+
+@pytest.mark.parametrize("name", ["cornell_smoke_box", "cover2"])
+def test_scene_from_a_file_renders_the_same_picture(name, tmp_path):
+    """save_scene(F=float64) + DeviceScene.from_file(F=float64): the picture of the scene that came back from the file
+    is, bit for bit, the picture of the scene it was written from"""
+    world, kw = rt.get_scene(name, spp=4, F=F)
+    cam, pat, bg = kw["camera"], kw["pattern"], kw["background"]
+    W, Hh = 40, 28
+    dev = rt.DeviceScene(world, F=F)
+    try:
+        want, _ = dev.render(cam, pat, bg, W, Hh)
+    finally:
+        dev.close()
+    path = tmp_path / "scene.rtscene64"
+    rt.save_scene(path, world, F=F)
+    loaded = rt.DeviceScene.from_file(path, F=F)
+    try:
+        got, _ = loaded.render(cam, pat, bg, W, Hh)
+    finally:
+        loaded.close()
+    assert got.dtype == F
+    np.testing.assert_array_equal(bits(got), bits(want))
+    with pytest.raises(ffi.RtError):
+        rt.DeviceScene.from_file(path)
 
 
 def test_group_of_float64_scenes(monkeypatch):

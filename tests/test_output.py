@@ -6,6 +6,7 @@ import zlib
 import numpy as np
 
 import raytracing_amd as rt
+from raytracing_amd import _ffi as ffi
 
 F = np.float32
 
@@ -40,6 +41,26 @@ def test_quantisation_matches_n0f8():
     np.testing.assert_array_equal(got, want)
     assert list(got[0, :5, 0]) == [0, 0, 0, 2, 2]           # ties go to the even neighbour
     assert got[0, 9, 0] == 255 and got[0, 10, 0] == 0 and got[0, 11, 0] == 255
+
+
+def test_quantisation_of_a_float64_image_is_done_in_double():
+    # N0f8(x::Float64): x * 255 and the rounding in double; the Float32 product of the same values rounds some the other way
+    rng = np.random.default_rng(11)
+    k = rng.integers(0, 255, 4000)
+    vals = np.concatenate([(k + 0.5) / 255.0, np.nextafter((k + 0.5) / 255.0, 0), np.nextafter((k + 0.5) / 255.0, 1),
+                           rng.random(4000) * 1.2 - 0.1, [np.nan, np.inf, -np.inf, -0.0, 1.0]])
+    img = np.zeros((2, len(vals), 3), np.float64)
+    img[0, :, 0] = vals
+    img[1, :, 2] = vals[::-1]
+    got = rt.to_rgb8(img)
+    want = np.rint(rt.clamp01(img) * 255.0).astype(np.uint8)
+    assert rt.clamp01(img).dtype == np.float64
+    np.testing.assert_array_equal(got, want)
+    assert np.any(got != rt.to_rgb8(img.astype(F)))
+    L = ffi.lib()
+    rgb = np.zeros(12, np.uint8)
+    assert L.rt_image_to_rgb8_f64(None, 2, 2, ffi.bptr(rgb)) == -1
+    assert L.rt_image_to_rgb8_f64(ffi.dptr(np.zeros(12)), 0, 2, ffi.bptr(rgb)) == -1
 
 
 def test_png_and_ppm_round_trip(tmp_path):

@@ -69,3 +69,46 @@ def test_damaged_files_are_turned_down(tmp_path):
     assert L.rt_scene_desc_load(os.fsencode(tmp_path / "missing.rtscene"), C.byref(desc)) == -1
     assert b"cannot open" in L.rt_last_error()
     L.rt_scene_desc_free(None)   # a null description is ignored
+
+
+@pytest.mark.parametrize("name", ["cornell_smoke_box", "cover2", "teapot"])
+def test_float64_descriptions_round_trip(name, tmp_path):
+    """rt_scene_desc_save_f64 / _load_f64: the tables come back value for value, saving them again gives the same bytes,
+    and each loader turns the other element type's file down"""
+    from raytracing_amd import hittables as H
+    from raytracing_amd.scene_manager import SceneManager, build_bvh_scene, flatten_scene
+    world, kw = rt.get_scene(name, spp=1, F=np.float64)
+    path = tmp_path / (name + ".rtscene64")
+    rt.save_scene(path, world, F=np.float64)
+    with H.element_type(np.float64):
+        want, keep = flatten_scene(world, build_bvh_scene(SceneManager(world)))
+    L = ffi.lib()
+    desc = C.POINTER(ffi.rtSceneDesc64)()
+    ffi.check(L.rt_scene_desc_load_f64(os.fsencode(path), C.byref(desc)))
+    try:
+        d = desc.contents
+        for f in ("n_objects", "n_top", "n_transforms", "n_materials", "n_textures", "n_images", "n_perlins", "n_meshes",
+                  "n_groups", "n_buckets"):
+            assert getattr(d, f) == getattr(want, f), f
+        assert C.string_at(d.objects, d.n_objects * C.sizeof(ffi.rtObject64)) == \
+               C.string_at(want.objects, want.n_objects * C.sizeof(ffi.rtObject64))
+        for b in range(d.n_buckets):
+            got_t, want_t = d.buckets[b], want.buckets[b]
+            assert (got_t.kind, got_t.n_objects, got_t.n_nodes) == (want_t.kind, want_t.n_objects, want_t.n_nodes)
+            assert C.string_at(got_t.node_bounds, 48 * got_t.n_nodes) == C.string_at(want_t.node_bounds, 48 * want_t.n_nodes)
+            assert C.string_at(got_t.node_leaf, got_t.n_nodes) == C.string_at(want_t.node_leaf, want_t.n_nodes)
+        again = tmp_path / "again.rtscene64"
+        ffi.check(L.rt_scene_desc_save_f64(desc, os.fsencode(again)))
+    finally:
+        L.rt_scene_desc_free_f64(desc)
+    assert again.read_bytes() == path.read_bytes()
+    # the file carries its element type
+    d32, d64 = C.POINTER(ffi.rtSceneDesc)(), C.POINTER(ffi.rtSceneDesc64)()
+    assert L.rt_scene_desc_load(os.fsencode(path), C.byref(d32)) == -1 and not d32
+    assert b"element type" in L.rt_last_error()
+    rt.save_scene(tmp_path / "f32.rtscene", rt.get_scene(name, spp=1)[0])
+    assert L.rt_scene_desc_load_f64(os.fsencode(tmp_path / "f32.rtscene"), C.byref(d64)) == -1 and not d64
+    assert L.rt_scene_desc_load_f64(os.fsencode(tmp_path / "missing"), C.byref(d64)) == -1
+    assert L.rt_scene_desc_save_f64(None, os.fsencode(again)) == -1
+    L.rt_scene_desc_free_f64(None)
+    del keep
