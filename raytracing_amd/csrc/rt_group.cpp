@@ -120,8 +120,8 @@ struct Group {
             return rt_fail(e_ == hipErrorOutOfMemory ? RT_ENOMEM : RT_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-template <class P>
-int group_destroy(Group<P>* g) {
+template <class P, class H> // H: the handle type of the C ABI (a Group<P> under its public name)
+int group_destroy(H* g) {
     if (!g) return RT_OK;
     const Rccl* R = g->comms.empty() ? nullptr : rccl();
     for (size_t k = 0; k < g->devices.size(); ++k) {
@@ -136,15 +136,15 @@ int group_destroy(Group<P>* g) {
     return RT_OK;
 }
 
-template <class P>
-int group_create(const typename P::Desc* desc, const int* devices, int n_devices, Group<P>** out) {
+template <class P, class H>
+int group_create(const typename P::Desc* desc, const int* devices, int n_devices, H** out) {
     if (!desc || !out) return rt_fail(RT_EINVAL, "rt_group_create: null argument");
     *out = nullptr;
     if (n_devices < 0 || (n_devices > 0 && !devices)) return rt_fail(RT_EINVAL, "rt_group_create: bad device list");
     int visible = 0;
     hipError_t e = hipGetDeviceCount(&visible);
     if (e != hipSuccess || visible == 0) return rt_fail(RT_ENODEV, "no HIP device available (%s)", hipGetErrorString(e));
-    Group<P>* g = new (std::nothrow) Group<P>();
+    H* g = new (std::nothrow) H();
     if (!g) return rt_fail(RT_ENOMEM, "out of host memory");
     if (n_devices == 0) for (int d = 0; d < visible; ++d) g->devices.push_back(d);
     else g->devices.assign(devices, devices + n_devices);
@@ -167,7 +167,7 @@ int group_create(const typename P::Desc* desc, const int* devices, int n_devices
             st = rt_fail(RT_EHIP, "hipStreamCreate failed on device %d", g->devices[k]);
         if (st != RT_OK) {
             const std::string msg = rt_last_error();
-            group_destroy(g);
+            group_destroy<P, H>(g);
             return rt_fail(st, "%s", msg.c_str());
         }
     }
@@ -278,12 +278,9 @@ struct rtGroup64 : Group<Float64Path> {};
 
 extern "C" {
 
-int rt_group_destroy(rtGroup* g) { return group_destroy<Float32Path>(g); }
+int rt_group_destroy(rtGroup* g) { return group_destroy<Float32Path, rtGroup>(g); }
 int rt_group_create(const rtSceneDesc* desc, const int* devices, int n_devices, rtGroup** out) {
-    Group<Float32Path>* g = nullptr;
-    int st = group_create<Float32Path>(desc, devices, n_devices, &g);
-    if (out) *out = static_cast<rtGroup*>(g);
-    return st;
+    return group_create<Float32Path, rtGroup>(desc, devices, n_devices, out);
 }
 int rt_group_size(const rtGroup* g, int* n_devices) {
     if (!g || !n_devices) return rt_fail(RT_EINVAL, "rt_group_size: null argument");
@@ -296,12 +293,9 @@ int rt_group_render(rtGroup* g, const rtCamera* camera, const float* pattern, in
 }
 
 // the same for render(Float64, ...): the members are Float64 scenes, the accumulators doubles (ncclDouble)
-int rt_group_destroy_f64(rtGroup64* g) { return group_destroy<Float64Path>(g); }
+int rt_group_destroy_f64(rtGroup64* g) { return group_destroy<Float64Path, rtGroup64>(g); }
 int rt_group_create_f64(const rtSceneDesc64* desc, const int* devices, int n_devices, rtGroup64** out) {
-    Group<Float64Path>* g = nullptr;
-    int st = group_create<Float64Path>(desc, devices, n_devices, &g);
-    if (out) *out = static_cast<rtGroup64*>(g);
-    return st;
+    return group_create<Float64Path, rtGroup64>(desc, devices, n_devices, out);
 }
 int rt_group_size_f64(const rtGroup64* g, int* n_devices) {
     if (!g || !n_devices) return rt_fail(RT_EINVAL, "rt_group_size_f64: null argument");

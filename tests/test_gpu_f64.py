@@ -294,6 +294,17 @@ def test_group_of_float64_scenes(monkeypatch):
         assert np.array_equal(rt.render("cornell_smoke_box", gpu=True, spp=6, width=W, height=Hh, devices=[0, 0], F=F), img)
     finally:
         two.close()
+    # more members than pattern columns: the member without a column adds a zero sum
+    three = rt.DeviceGroup(world, devices=[0, 0, 0], F=F)
+    dev = rt.DeviceScene(world, F=F)
+    try:
+        img, st = three.render(cam, pat[:, :2], bg, W, Hh)
+        want2, _ = dev.render(cam, pat[:, :2], bg, W, Hh)
+        assert st.paths == W * Hh * 2
+        np.testing.assert_allclose(img, want2, rtol=1e-13, atol=1e-300)
+    finally:
+        three.close()
+        dev.close()
 
 
 def test_bad_arguments_are_errors():
