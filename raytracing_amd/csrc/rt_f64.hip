@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <new>
 #include <vector>
 
 #include "../../include/rt_amd.h"
@@ -1381,8 +1382,8 @@ const int R64_SYNC_EVERY = 8;
 const int R64_MAX_POOLS = 4, R64_POOLS_DEFAULT = 3; // pools of slots, each on a stream of its own (three: with the caller's
                                                     // stream that leaves one of the four hardware queues of a process to others; a fifth stream made four pools lose a quarter)
 
-int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n, int first, int stride, const real* bg, int width, int height,
-                 int max_depth, uint64_t seed, real* d_accum, hipStream_t stream) {
+int accumulate64_run(rtScene64* s, const rtCamera64* cam, const real* pattern, int n, int first, int stride, const real* bg, int width, int height,
+                     int max_depth, uint64_t seed, real* d_accum, hipStream_t stream) {
     size_t pixels = (size_t)width * (size_t)height;
     int count = first < n ? (n - first + stride - 1) / stride : 0;
     if (count == 0 || max_depth <= 0) { // no column of this shard, or trace() returns zero(Vec3) at once
@@ -1411,8 +1412,8 @@ int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n
     F.first = first; F.stride = stride;
     F.bg[0] = bg[0]; F.bg[1] = bg[1]; F.bg[2] = bg[2];
     F.seed32 = fold_seed(seed);
-    // Two half pools on two streams: a launch of the extend kernel ends with the few workgroups whose rays walk longest
-    // and the rest of the GPU idle; the other half's kernels fill that time.
+    // Several pools on a stream each: a launch of the extend kernel ends with the few workgroups whose rays walk longest
+    // and the rest of the GPU idle; the other pools' kernels fill that time.
     int n_pools = R64_POOLS_DEFAULT;
     if (const char* e = getenv("RT_AMD_F64_POOLS"))
         if (atoi(e) >= 1 && atoi(e) <= R64_MAX_POOLS) n_pools = atoi(e);
@@ -1508,6 +1509,15 @@ int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n
     return RT_OK;
 }
 
+// A frame that fails part-way has kernels on the pools' streams that the caller's stream no longer waits for: they are
+// drained before the error is handed back, so that the caller may free or reuse the accumulator at once.
+int accumulate64(rtScene64* s, const rtCamera64* cam, const real* pattern, int n, int first, int stride, const real* bg, int width, int height,
+                 int max_depth, uint64_t seed, real* d_accum, hipStream_t stream) {
+    int st = accumulate64_run(s, cam, pattern, n, first, stride, bg, width, height, max_depth, seed, d_accum, stream);
+    if (st != RT_OK) (void)hipDeviceSynchronize();
+    return st;
+}
+
 } // namespace
 
 extern "C" void rt64_launch_add(double* d_dst, const double* d_src, size_t n, hipStream_t stream) {
@@ -1527,7 +1537,8 @@ extern "C" int rt_scene_create_f64(const rtSceneDesc64* desc, int device, rtScen
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return rt_fail(RT_ENODEV, "rt_scene_create_f64: no HIP device");
     if (device < 0 || device >= count) return rt_fail(RT_EINVAL, "rt_scene_create_f64: device %d out of range (0..%d)", device, count - 1);
     HIP_TRY64(hipSetDevice(device));
-    rtScene64* s = new rtScene64();
+    rtScene64* s = new (std::nothrow) rtScene64();
+    if (!s) return rt_fail(RT_ENOMEM, "rt_scene_create_f64: out of host memory");
     s->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->n_cus = prop.multiProcessorCount;

@@ -87,7 +87,8 @@ class DeviceScene:
 
     def __init__(self, world, device=0, F=np.float32):
         """F: the element type of render(F, ...) (main.jl:21): numpy.float32, or numpy.float64 for the Float64 entry
-        points (rt_*_f64: render, accumulate, finalize and the two parity hooks; the other methods are Float32 only)."""
+        points (rt_*_f64: render, accumulate, finalize, the 8-bit output stage and the two parity hooks; layout() and
+        pairs() show the Float32 path's acceleration structure and exist for it only)."""
         self.rec = ffi.records(F)
         self.F = self.rec.np_type
         self.world = list(world)
