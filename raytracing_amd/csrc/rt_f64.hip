@@ -1042,6 +1042,33 @@ __global__ __launch_bounds__(R64_BLOCK) void rt64_shade_kernel(Scene64 S, Frame6
     if (lane == 0 && alive_mask) atomicAdd(live, (uint32_t)__popcll(alive_mask));
 }
 
+// The slots that still hold a path, moved to the front of a smaller pool (dst, whose depth plane the host has set to
+// -1): once the last path of a batch has been handed out a pool only empties, and without this every launch until the
+// longest path ends runs nearly all of its waves for a few lanes each.  Runs between a shade and an extend launch, so
+// the hit planes hold nothing that is still needed.  A path's arithmetic does not depend on the slot it sits in.
+__global__ __launch_bounds__(R64_BLOCK) void rt64_compact_kernel(Pool64 src, Pool64 dst, uint32_t* taken) {
+    const uint32_t slot = blockIdx.x * R64_BLOCK + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
+    const size_t N = src.n_slots, M = dst.n_slots;
+    const int depth = slot < src.n_slots ? src.i[PI_DEPTH * N + slot] : -1;
+    const bool alive = depth > 0;
+    const unsigned long long mask = __ballot(alive);
+    if (!mask) return;
+    const unsigned leader = (unsigned)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(taken, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, (int)leader);
+    if (!alive) return;
+    const size_t to = (size_t)base + (size_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (to >= M) return; // (the host sizes dst by a count taken when at least as many slots held a path)
+    for (int p = PD_O; p < PD_T; ++p) dst.d[p * M + to] = src.d[p * N + slot];
+    dst.i[PI_DEPTH * M + to] = depth;
+    dst.i[PI_PIXEL * M + to] = src.i[PI_PIXEL * N + slot];
+    dst.i[PI_SAMPLE * M + to] = src.i[PI_SAMPLE * N + slot];
+    dst.i[PI_PATH_LO * M + to] = src.i[PI_PATH_LO * N + slot];
+    dst.i[PI_PATH_HI * M + to] = src.i[PI_PATH_HI * N + slot];
+}
+
 // accum (Julia Array{RGB{Float64}}(H, W) order) += the batch's radiances, column after column: the sample loop of draw!
 __global__ void rt64_sum_kernel(const real* radiance, int batch_cols, int width, int height, int first_batch, real* accum) {
     int pixel = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1113,6 +1140,7 @@ struct rtScene64 {
     int32_t* d_pool_i = nullptr; size_t pool_i_cap = 0; // ... and int planes
     uint32_t* d_live = nullptr;                        // per half pool R64_SYNC_EVERY counters of slots alive after a shade launch
     uint32_t* h_live = nullptr;                        // pinned mirror
+    uint32_t* d_taken = nullptr;                       // per pool R64_MAX_COMPACTIONS counters of rt64_compact_kernel
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr}; // the streams of the pools after the first
     hipEvent_t fork = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t read[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}}; // counters of a batch are on the host
@@ -1379,6 +1407,7 @@ const size_t R64_RADIANCE_BUDGET = (size_t)8 << 30;
 // slots of the pool (156 bytes each); bounce launches between two looks at the live counter
 const uint32_t R64_MAX_SLOTS = 3u << 19; // 1.5 Mi: the best of 1, 1.5, 2, 3 and 4 Mi with four pools
 const int R64_SYNC_EVERY = 8;
+const int R64_MAX_COMPACTIONS = 64; // per pool and batch of columns (each takes a quarter off or more: 1.5 Mi slots are down to one workgroup's after 33)
 const int R64_MAX_POOLS = 4, R64_POOLS_DEFAULT = 3; // pools of slots, each on a stream of its own (three: with the caller's
                                                     // stream that leaves one of the four hardware queues of a process to others; a fifth stream made four pools lose a quarter)
 
@@ -1402,6 +1431,10 @@ int accumulate64_run(rtScene64* s, const rtCamera64* cam, const real* pattern, i
     if (!s->d_next) HIP_TRY64(hipMalloc((void**)&s->d_next, sizeof(unsigned long long)));
     if (!s->d_live) HIP_TRY64(hipMalloc((void**)&s->d_live, 2 * R64_MAX_POOLS * R64_SYNC_EVERY * sizeof(uint32_t)));
     if (!s->h_live) HIP_TRY64(hipHostMalloc((void**)&s->h_live, 2 * R64_MAX_POOLS * R64_SYNC_EVERY * sizeof(uint32_t)));
+    if (!s->d_taken) HIP_TRY64(hipMalloc((void**)&s->d_taken, R64_MAX_POOLS * R64_MAX_COMPACTIONS * sizeof(uint32_t)));
+    const bool compacting = !getenv("RT_AMD_F64_NO_COMPACT"); // for measurements
+    int sixteenths = 12;
+    if (const char* e = getenv("RT_AMD_F64_COMPACT_AT")) if (atoi(e) >= 1 && atoi(e) <= 16) sixteenths = atoi(e);
     uint32_t max_slots = R64_MAX_SLOTS;
     if (const char* e = getenv("RT_AMD_F64_SLOTS")) // for tests and tuning
         if (atoi(e) > 0) max_slots = (uint32_t)atoi(e);
@@ -1437,11 +1470,14 @@ int accumulate64_run(rtScene64* s, const rtCamera64* cam, const real* pattern, i
         uint32_t total_slots = (uint32_t)std::min<unsigned long long>((want_slots + R64_BLOCK - 1) / R64_BLOCK * R64_BLOCK, max_slots);
         const int pools = total_slots >= 64u * R64_BLOCK ? n_pools : 1;
         const uint32_t per = (total_slots / pools + R64_BLOCK - 1) / R64_BLOCK * R64_BLOCK;
-        st = grow64(&s->d_pool, &s->pool_cap, (size_t)PD_PLANES * per * pools);
-        if (st == RT_OK) st = grow64(&s->d_pool_i, &s->pool_i_cap, (size_t)PI_PLANES * per * pools);
+        // every pool twice: the second copy is where a pool is compacted to (and back from) once the batch runs out of paths
+        st = grow64(&s->d_pool, &s->pool_cap, (size_t)PD_PLANES * per * pools * 2);
+        if (st == RT_OK) st = grow64(&s->d_pool_i, &s->pool_i_cap, (size_t)PI_PLANES * per * pools * 2);
         if (st != RT_OK) return st;
-        Pool64 pool[R64_MAX_POOLS];
+        Pool64 pool[R64_MAX_POOLS], spare[R64_MAX_POOLS];
         hipStream_t on[R64_MAX_POOLS];
+        dim3 grid[R64_MAX_POOLS];
+        int compactions[R64_MAX_POOLS];
         on[0] = stream;
         for (int h = 1; h < pools; ++h) on[h] = s->side[h];
         for (int h = 0; h < pools; ++h) {
@@ -1449,16 +1485,22 @@ int accumulate64_run(rtScene64* s, const rtCamera64* cam, const real* pattern, i
             pool[h].pad = 0;
             pool[h].d = s->d_pool + (size_t)h * PD_PLANES * per;
             pool[h].i = s->d_pool_i + (size_t)h * PI_PLANES * per;
+            spare[h] = pool[h];
+            spare[h].d += (size_t)pools * PD_PLANES * per;
+            spare[h].i += (size_t)pools * PI_PLANES * per;
+            grid[h] = dim3((per + R64_BLOCK - 1) / R64_BLOCK);
+            compactions[h] = 0;
         }
-        const dim3 grid((per + R64_BLOCK - 1) / R64_BLOCK), block(R64_BLOCK);
+        const dim3 block(R64_BLOCK);
         HIP_TRY64(hipMemsetAsync(s->d_next, 0, sizeof(unsigned long long), stream));
+        HIP_TRY64(hipMemsetAsync(s->d_taken, 0, R64_MAX_POOLS * R64_MAX_COMPACTIONS * sizeof(uint32_t), stream));
         if (pools > 1) { // the side streams start after what the caller's stream holds so far
             HIP_TRY64(hipEventRecord(s->fork, stream));
             for (int h = 1; h < pools; ++h) HIP_TRY64(hipStreamWaitEvent(s->side[h], s->fork, 0));
         }
         for (int h = 0; h < pools; ++h) {
             HIP_TRY64(hipMemsetAsync(pool[h].i, 0, (size_t)per * sizeof(int32_t), on[h])); // depth plane: every slot wants a path
-            hipLaunchKernelGGL(rt64_shade_kernel, grid, block, 0, on[h], s->dev, F, pool[h], s->d_next, s->d_radiance,
+            hipLaunchKernelGGL(rt64_shade_kernel, grid[h], block, 0, on[h], s->dev, F, pool[h], s->d_next, s->d_radiance,
                                s->d_live + (h * 2 + 1) * R64_SYNC_EVERY); // the first paths (its count is not read)
         }
         // every path ends within max_depth bounces of its start, and a launch that starts none ends the frame soon after:
@@ -1479,9 +1521,9 @@ int accumulate64_run(rtScene64* s, const rtCamera64* cam, const real* pattern, i
             for (int k = 0; k < R64_SYNC_EVERY; ++k)
                 for (int h = 0; h < pools; ++h) {
                     if (done[h]) continue;
-                    if (s->dev.n_groups > 0) hipLaunchKernelGGL(rt64_extend_kernel<true>, grid, block, 0, on[h], s->dev, F, pool[h]);
-                    else hipLaunchKernelGGL(rt64_extend_kernel<false>, grid, block, 0, on[h], s->dev, F, pool[h]);
-                    hipLaunchKernelGGL(rt64_shade_kernel, grid, block, 0, on[h], s->dev, F, pool[h], s->d_next, s->d_radiance,
+                    if (s->dev.n_groups > 0) hipLaunchKernelGGL(rt64_extend_kernel<true>, grid[h], block, 0, on[h], s->dev, F, pool[h]);
+                    else hipLaunchKernelGGL(rt64_extend_kernel<false>, grid[h], block, 0, on[h], s->dev, F, pool[h]);
+                    hipLaunchKernelGGL(rt64_shade_kernel, grid[h], block, 0, on[h], s->dev, F, pool[h], s->d_next, s->d_radiance,
                                        live_at(s->d_live, h, parity) + k);
                 }
             HIP_TRY64(hipGetLastError());
@@ -1495,7 +1537,25 @@ int accumulate64_run(rtScene64* s, const rtCamera64* cam, const real* pattern, i
             for (int h = 0; h < pools; ++h) { // the batch before this one
                 if (done[h]) continue;
                 HIP_TRY64(hipEventSynchronize(s->read[h][parity ^ 1]));
-                done[h] = live_at(s->h_live, h, parity ^ 1)[R64_SYNC_EVERY - 1] == 0;
+                const uint32_t held = live_at(s->h_live, h, parity ^ 1)[R64_SYNC_EVERY - 1];
+                done[h] = held == 0;
+                // Fewer paths than slots after a launch: a slot asked for a path and there was none, so the batch has
+                // handed out its last and the pool only empties from here on -- `held`, a batch of launches old, bounds
+                // what it holds now.  At three quarters or less the paths move to the front of the pool's other copy
+                // and the launches shrink to it (after the batch already in the stream).
+                const uint32_t fit = (held + R64_BLOCK - 1) / R64_BLOCK * R64_BLOCK;
+                if (compacting && held > 0 && (unsigned long long)held * 16ull <= (unsigned long long)pool[h].n_slots * (unsigned long long)sixteenths &&
+                    fit < pool[h].n_slots && compactions[h] < R64_MAX_COMPACTIONS) {
+                    Pool64 to = spare[h];
+                    to.n_slots = fit;
+                    HIP_TRY64(hipMemsetAsync(to.i + (size_t)PI_DEPTH * fit, 0xFF, (size_t)fit * sizeof(int32_t), on[h])); // depth -1: no path, none to come
+                    hipLaunchKernelGGL(rt64_compact_kernel, grid[h], block, 0, on[h], pool[h], to, s->d_taken + h * R64_MAX_COMPACTIONS + compactions[h]);
+                    HIP_TRY64(hipGetLastError());
+                    spare[h].d = pool[h].d; spare[h].i = pool[h].i;
+                    pool[h] = to;
+                    grid[h] = dim3(fit / R64_BLOCK);
+                    ++compactions[h];
+                }
             }
         }
         for (int h = 1; h < pools; ++h) { // the caller's stream goes on after the side streams' last kernels
@@ -1576,6 +1636,7 @@ extern "C" int rt_scene_destroy_f64(rtScene64* s) {
     if (s->d_pool_i) (void)hipFree(s->d_pool_i);
     if (s->d_live) (void)hipFree(s->d_live);
     if (s->h_live) (void)hipHostFree(s->h_live);
+    if (s->d_taken) (void)hipFree(s->d_taken);
     for (int h = 0; h < 4; ++h) {
         if (s->side[h]) (void)hipStreamDestroy(s->side[h]);
         if (s->join[h]) (void)hipEventDestroy(s->join[h]);

@@ -215,6 +215,29 @@ def test_progressive_rendering_and_resume_in_float64(tmp_path):
         dev.close()
 
 
+def test_compacted_pool_gives_the_same_picture(monkeypatch):
+    """Once a batch has handed out its last path the pools are compacted as they empty (rt64_compact_kernel); a path's
+    arithmetic does not depend on its slot, so the picture is that of the pools left as they are -- and the oracle's"""
+    world, kw = rt.get_scene("cornell_smoke_box", spp=12, F=F)   # long paths inside the media: a long tail of few paths
+    cam, pat, bg = kw["camera"], kw["pattern"], kw["background"]
+    W, Hh = 96, 64
+    dev = rt.DeviceScene(world, F=F)
+    try:
+        got, _ = dev.render(cam, pat, bg, W, Hh)
+        monkeypatch.setenv("RT_AMD_F64_NO_COMPACT", "1")
+        plain, _ = dev.render(cam, pat, bg, W, Hh)
+        monkeypatch.delenv("RT_AMD_F64_NO_COMPACT")
+        monkeypatch.setenv("RT_AMD_F64_COMPACT_AT", "16")          # at every look
+        monkeypatch.setenv("RT_AMD_F64_SLOTS", "8192")             # and with paths still to hand out for most of the frame
+        eager, _ = dev.render(cam, pat, bg, W, Hh)
+    finally:
+        dev.close()
+    np.testing.assert_array_equal(bits(got), bits(plain))
+    np.testing.assert_array_equal(bits(eager), bits(plain))
+    want = O.OracleScene(world, F=F).render(cam, pat, bg, W, Hh)
+    np.testing.assert_array_equal(bits(got), bits(want))
+
+
 def test_device_output_stage_matches_host_quantisation():
     """rt_finalize_rgb8_f64 (clamp01 + N0f8 in double on the device) == rt_finalize_f64 followed by the host's"""
     import torch
