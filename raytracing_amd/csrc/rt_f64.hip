@@ -49,6 +49,15 @@ struct __align__(64) Node64 { // src/BVH.jl:5-10 (one 64-byte line: four 16-byte
     int32_t left, right; // 1-based node ids / object positions, as the reference stores them
     int32_t leaf, first; // first: the object at position `left` of a leaf of a tree over objects
 };
+// What the walk of a tree over objects reads of a node: the box narrowed to float and the links, half a Node64.  The
+// float box decides the reference's box test wherever the rounding of its planes cannot matter (box_verdict32); where
+// it can, the walk reads the node's Node64 and decides as before.  inner node: left, right > 0, the children's ids;
+// leaf of one object (every leaf of a tree the reference builds): left = the object, right = -1; leaf of the objects at
+// positions l..r: left = l, right = -1 - r.
+struct __align__(32) Node32 {
+    float box[6];
+    int32_t left, right;
+};
 // What a walk needs of one object, in one record: a plain object as it is, a Transform around a plain object as that
 // object with the matrix that takes the ray to it.  The walk reaches a leaf's test after two dependent fetches (node,
 // this record) instead of four (node, object list, object, transform and wrapped object).
@@ -86,6 +95,7 @@ struct Scene64 {
     const int32_t* tri_ids;
     const int32_t* mesh_materials;
     const Node64* nodes;
+    const Node32* nodes32;     // node for node beside `nodes`
     const int32_t* tree_objects;
     const Tree64* trees;       // the type groups of the SceneManager in order, then the nested trees
     const uint8_t* mat_uv;     // per material: 1 if its texture can read (u, v) (an image texture, possibly through checkers)
@@ -345,6 +355,52 @@ __device__ inline bool hit_aabb_fast(const real* b, const Ray& r, const V3& inv,
     return true;
 }
 __device__ inline V3 reciprocal(V3 d) { return v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
+
+// hit_aabb_fast on a box whose planes were rounded to float: 1 the reference's test passes, 0 it fails, -1 not certain
+// (take the planes in double).  A plane b read as float is off by at most 2^-24 |b|, its distance (b - o) * inv by that
+// times |inv|; slack.x/y/z hold 2^-22 |inv| (a float, rounded, at least the smallest normal float, Inf for a zero
+// direction component), so e below is more than twice what either end of the interval can be off by because of the
+// narrowing; the 2^-50 term covers the reciprocals as in hit_aabb_fast.  NaN distances are ignored by the
+// comparisons here exactly as they are in the reference's.
+struct Slack { float x, y, z; };
+__device__ inline Slack box_slack(const V3& inv) {
+    const float least = 1.17549435e-38f;
+    Slack k;
+    k.x = fmaxf((float)(fabs(inv.x) * 2.384185791015625e-07), least);
+    k.y = fmaxf((float)(fabs(inv.y) * 2.384185791015625e-07), least);
+    k.z = fmaxf((float)(fabs(inv.z) * 2.384185791015625e-07), least);
+    return k;
+}
+__device__ inline int box_verdict32(const Node32& q, const Ray& r, const V3& inv, const Slack& k, real t_min, real t_max) {
+    const real TOL = 8.881784197001252e-16; // 2^-50
+    real lo = ((real)q.box[0] - r.o.x) * inv.x, hi = ((real)q.box[3] - r.o.x) * inv.x;
+    if (lo > hi) { real s = lo; lo = hi; hi = s; }
+    if (hi < t_max) t_max = hi;
+    if (lo > t_min) t_min = lo;
+    float e = fmaxf(fabsf(q.box[0]), fabsf(q.box[3])) * k.x;
+    real gap = t_max - t_min, tol = (real)e + TOL * (fabs(t_max) + fabs(t_min)) + 1e-300;
+    if (gap < -tol) return 0;
+    if (!(gap > tol)) return -1;
+
+    lo = ((real)q.box[1] - r.o.y) * inv.y; hi = ((real)q.box[4] - r.o.y) * inv.y;
+    if (lo > hi) { real s = lo; lo = hi; hi = s; }
+    if (hi < t_max) t_max = hi;
+    if (lo > t_min) t_min = lo;
+    e = fmaxf(e, fmaxf(fabsf(q.box[1]), fabsf(q.box[4])) * k.y);
+    gap = t_max - t_min; tol = (real)e + TOL * (fabs(t_max) + fabs(t_min)) + 1e-300;
+    if (gap < -tol) return 0;
+    if (!(gap > tol)) return -1;
+
+    lo = ((real)q.box[2] - r.o.z) * inv.z; hi = ((real)q.box[5] - r.o.z) * inv.z;
+    if (lo > hi) { real s = lo; lo = hi; hi = s; }
+    if (hi < t_max) t_max = hi;
+    if (lo > t_min) t_min = lo;
+    e = fmaxf(e, fmaxf(fabsf(q.box[2]), fabsf(q.box[5])) * k.z);
+    gap = t_max - t_min; tol = (real)e + TOL * (fabs(t_max) + fabs(t_min)) + 1e-300;
+    if (gap < -tol) return 0;
+    if (!(gap > tol)) return -1;
+    return 1;
+}
 
 // ------------------------------------------------------------------ primitives
 __device__ inline void get_sphere_uv(V3 p, real& u, real& v) { // src/sphere.jl:104-108
@@ -619,15 +675,21 @@ __device__ Lite hit_tree(const Scene64& S, int tree, const Ray& r, const V3& inv
     if (T.n_nodes == 0) return closest;
     int n = sp0;
     stk[(n++) * R64_BLOCK] = 1u;
+    const Slack slack = box_slack(inv);
     while (n > sp0) {
-        const Node64& node = S.nodes[(size_t)T.node_base + stk[(--n) * R64_BLOCK] - 1u];
-        if (!hit_aabb_fast(node.box, r, inv, t_min, t_max)) continue;
-        if (node.leaf) {
+        const size_t at_node = (size_t)T.node_base + stk[(--n) * R64_BLOCK] - 1u;
+        const Node32 node = S.nodes32[at_node];
+        int pass = box_verdict32(node, r, inv, slack, t_min, t_max);
+        if (pass < 0) pass = hit_aabb_fast(S.nodes[at_node].box, r, inv, t_min, t_max) ? 1 : 0;
+        if (!pass) continue;
+        if (node.right < 0) {
             // src/hittable.jl:21-31 over objects[left:right]
             Lite lh = lite_miss();
             real tm = t_max;
-            for (int i = node.left; i <= node.right; ++i) {
-                int oi = i == node.left ? node.first : S.tree_objects[T.obj_base + i - 1];
+            const bool one = node.right == -1;
+            const int first = one ? 0 : node.left, last = one ? 0 : -1 - node.right;
+            for (int i = first; i <= last; ++i) {
+                int oi = one ? node.left : S.tree_objects[T.obj_base + i - 1];
                 int32_t inner = -1;
                 real inner_bound = R64_INF;
                 real t = hit_object_t<NESTED, GROUPS>(S, oi, r, t_min, tm, c, stk, n, inner, inner_bound);
@@ -1174,6 +1236,7 @@ struct Staged64 {
     std::vector<real> vertices;
     std::vector<int32_t> indices, tri_ids, mesh_materials;
     std::vector<Node64> nodes;
+    std::vector<Node32> nodes32;
     std::vector<int32_t> tree_objects;
     std::vector<Tree64> trees;
     std::vector<uint8_t> mat_uv;
@@ -1346,6 +1409,14 @@ int stage_scene64(const rtSceneDesc64& D, Staged64& H, int* stack_need) {
             n.leaf = T.node_leaf[i] == 1 ? 1 : 0;
             n.first = (n.leaf && T.kind == 0 && n.left >= 1 && n.left <= T.n_objects) ? T.objects[n.left - 1] : 0;
             H.nodes.push_back(n);
+            Node32 q;
+            for (int a = 0; a < 6; ++a) q.box[a] = (float)n.box[a]; // to nearest: what box_verdict32's bound assumes
+            q.left = n.left; q.right = n.right;
+            if (n.leaf && T.kind == 0) {
+                if (n.left == n.right) { q.left = n.first; q.right = -1; }
+                else q.right = -1 - n.right;
+            }
+            H.nodes32.push_back(q);
         }
         H.tree_objects.insert(H.tree_objects.end(), T.objects, T.objects + T.n_objects);
         H.trees.push_back(d);
@@ -1612,7 +1683,7 @@ extern "C" int rt_scene_create_f64(const rtSceneDesc64* desc, int device, rtScen
     UP64(objects, H.objects); UP64(fused, H.fused); UP64(top_pos, H.top_pos); UP64(transforms, H.transforms); UP64(materials, H.materials);
     UP64(textures, H.textures); UP64(images, H.images); UP64(texels, H.texels); UP64(perlins, H.perlins);
     UP64(meshes, H.meshes); UP64(vertices, H.vertices); UP64(indices, H.indices); UP64(tri_ids, H.tri_ids);
-    UP64(mesh_materials, H.mesh_materials); UP64(nodes, H.nodes); UP64(tree_objects, H.tree_objects); UP64(trees, H.trees);
+    UP64(mesh_materials, H.mesh_materials); UP64(nodes, H.nodes); UP64(nodes32, H.nodes32); UP64(tree_objects, H.tree_objects); UP64(trees, H.trees);
     UP64(mat_uv, H.mat_uv);
 #undef UP64
     d.n_buckets = desc->n_buckets;
