@@ -53,7 +53,8 @@ struct __align__(64) Node64 { // src/BVH.jl:5-10 (one 64-byte line: four 16-byte
 // float box decides the reference's box test wherever the rounding of its planes cannot matter (box_verdict32); where
 // it can, the walk reads the node's Node64 and decides as before.  inner node: left, right > 0, the children's ids;
 // leaf of one object (every leaf of a tree the reference builds): left = the object, right = -1; leaf of the objects at
-// positions l..r: left = l, right = -1 - r.
+// positions l..r: left = l, right = -1 - r.  Tree over meshes (src/mesh.jl:250-305): a leaf of either level keeps left
+// and holds right = -1 - r.
 struct __align__(32) Node32 {
     float box[6];
     int32_t left, right;
@@ -715,15 +716,20 @@ __device__ Lite hit_mesh_tree(const Scene64& S, int tree, const Ray& r, const V3
     int n = 1;
     stk[0] = 1u;
     int active_mesh_index = 0;
+    const Slack slack = box_slack(inv);
     while (n > 0) {
         if (active_mesh_index == n) {
             active_mesh_index = 0;
             n -= 1;
             continue;
         }
-        const Node64& node = S.nodes[(size_t)T.node_base + stk[(n - 1) * R64_BLOCK] - 1u];
+        const size_t at_node = (size_t)T.node_base + stk[(n - 1) * R64_BLOCK] - 1u;
+        const Node32 q = S.nodes32[at_node];
         n -= 1;
-        if (!hit_aabb_fast(node.box, r, inv, t_min, t_max)) continue;
+        int pass = box_verdict32(q, r, inv, slack, t_min, t_max);
+        if (pass < 0) pass = hit_aabb_fast(S.nodes[at_node].box, r, inv, t_min, t_max) ? 1 : 0;
+        if (!pass) continue;
+        struct { int left, right; bool leaf; } node = {q.left, q.right < 0 ? -1 - q.right : q.right, q.right < 0}; // (a leaf of a tree over meshes: right = -1 - r)
         if (node.leaf) {
             if (active_mesh_index == 0) {
                 stk[(n++) * R64_BLOCK] = (uint32_t)node.right;
@@ -1415,6 +1421,8 @@ int stage_scene64(const rtSceneDesc64& D, Staged64& H, int* stack_need) {
             if (n.leaf && T.kind == 0) {
                 if (n.left == n.right) { q.left = n.first; q.right = -1; }
                 else q.right = -1 - n.right;
+            } else if (n.leaf) { // tree over meshes: left stays, right = -1 - r for either kind of leaf
+                q.right = -1 - n.right;
             }
             H.nodes32.push_back(q);
         }
