@@ -361,7 +361,9 @@ __device__ inline V3 reciprocal(V3 d) { return v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.
 // (take the planes in double).  A plane b read as float is off by at most 2^-24 |b|, its distance (b - o) * inv by that
 // times |inv|; slack.x/y/z hold 2^-22 |inv| (a float, rounded, at least the smallest normal float, Inf for a zero
 // direction component), so e below is more than twice what either end of the interval can be off by because of the
-// narrowing; the 2^-50 term covers the reciprocals as in hit_aabb_fast.  NaN distances are ignored by the
+// narrowing; the 2^-50 term covers the reciprocals as in hit_aabb_fast.  A plane closer to zero than the smallest normal
+// float is off by up to 2^-150 instead: planes count as at least 1 in e, which covers that and keeps the product a normal
+// float.  NaN distances are ignored by the
 // comparisons here exactly as they are in the reference's.
 struct Slack { float x, y, z; };
 __device__ inline Slack box_slack(const V3& inv) {
@@ -378,7 +380,7 @@ __device__ inline int box_verdict32(const Node32& q, const Ray& r, const V3& inv
     if (lo > hi) { real s = lo; lo = hi; hi = s; }
     if (hi < t_max) t_max = hi;
     if (lo > t_min) t_min = lo;
-    float e = fmaxf(fabsf(q.box[0]), fabsf(q.box[3])) * k.x;
+    float e = fmaxf(fmaxf(fabsf(q.box[0]), fabsf(q.box[3])), 1.0f) * k.x;
     real gap = t_max - t_min, tol = (real)e + TOL * (fabs(t_max) + fabs(t_min)) + 1e-300;
     if (gap < -tol) return 0;
     if (!(gap > tol)) return -1;
@@ -387,7 +389,7 @@ __device__ inline int box_verdict32(const Node32& q, const Ray& r, const V3& inv
     if (lo > hi) { real s = lo; lo = hi; hi = s; }
     if (hi < t_max) t_max = hi;
     if (lo > t_min) t_min = lo;
-    e = fmaxf(e, fmaxf(fabsf(q.box[1]), fabsf(q.box[4])) * k.y);
+    e = fmaxf(e, fmaxf(fmaxf(fabsf(q.box[1]), fabsf(q.box[4])), 1.0f) * k.y);
     gap = t_max - t_min; tol = (real)e + TOL * (fabs(t_max) + fabs(t_min)) + 1e-300;
     if (gap < -tol) return 0;
     if (!(gap > tol)) return -1;
@@ -396,7 +398,7 @@ __device__ inline int box_verdict32(const Node32& q, const Ray& r, const V3& inv
     if (lo > hi) { real s = lo; lo = hi; hi = s; }
     if (hi < t_max) t_max = hi;
     if (lo > t_min) t_min = lo;
-    e = fmaxf(e, fmaxf(fabsf(q.box[2]), fabsf(q.box[5])) * k.z);
+    e = fmaxf(e, fmaxf(fmaxf(fabsf(q.box[2]), fabsf(q.box[5])), 1.0f) * k.z);
     gap = t_max - t_min; tol = (real)e + TOL * (fabs(t_max) + fabs(t_min)) + 1e-300;
     if (gap < -tol) return 0;
     if (!(gap > tol)) return -1;

@@ -192,6 +192,52 @@ def test_degenerate_rays_terminate_and_match(key):
         dev.close()
 
 
+def test_planes_outside_the_float_range_and_rays_that_graze():
+    """The walk reads the nodes' boxes narrowed to float and takes the double box wherever the narrowing could decide
+    the reference's test: spheres whose boxes lie beyond the float range, closer to zero than the smallest float, and at
+    coordinates where a float resolves less than their size; rays aimed at the boxes' faces, edges and corners"""
+    mat = rt.Material(rt.Lambertian, rt.Vec3(0.5, 0.5, 0.5))
+    rng = np.random.default_rng(5)
+    with H.element_type(F):
+        world = [rt.Sphere(rt.Vec3(1e39, 0, 0), 1e38, mat), rt.Sphere(rt.Vec3(-3e38, 1e39, 0), 2e38, mat),
+                 rt.Sphere(rt.Vec3(1e-40, 2e-40, -1e-40), 5e-41, mat), rt.Sphere(rt.Vec3(-3e-39, 0, 1e-39), 1e-39, mat)]
+        for k in range(60):   # float resolves 2^-24 * 1e6 = 0.06 here: boxes 0.02 to 2 across
+            c = rng.uniform(-1, 1, 3) * 50 + np.array([1e6, -1e6, 1e6])
+            world.append(rt.Sphere(rt.Vec3(*c), float(rng.uniform(0.01, 1.0)), mat))
+        for k in range(40):
+            c = rng.uniform(-40, 40, 3)
+            world.append(rt.Box(rt.Vec3(*c), rt.Vec3(*(c + rng.uniform(0.5, 6, 3))), mat))
+    ref = O.OracleScene(world, F=F)
+    dev = rt.DeviceScene(world, F=F)
+    try:
+        rays = []
+        targets = [np.array([1e39, 0, 0]), np.array([-3e38, 1e39, 0]), np.array([1e-40, 2e-40, -1e-40]), np.array([-3e-39, 0, 1e-39])]
+        for tgt in targets:
+            scale = max(np.abs(tgt).max(), 1e-300)
+            for _ in range(40):
+                o = tgt + rng.normal(0, 3, 3) * scale
+                rays.append(np.concatenate([o, (tgt + rng.normal(0, 0.12, 3) * scale) - o, [0.5]]))
+        for obj in world[4:]:
+            box6 = np.asarray(H.bounding_box(obj).as6(), dtype=F)
+            lo, hi = box6[:3], box6[3:]
+            for _ in range(12):
+                # a point on a face, an edge or a corner of the object's box, moved by nothing or by an ulp or two
+                p = np.where(rng.random(3) < 0.5, lo, hi).astype(F)
+                free = rng.random(3) < 0.4
+                p = np.where(free, lo + (hi - lo) * rng.random(3), p)
+                for _ in range(int(rng.integers(0, 3))):
+                    p = np.nextafter(p, p + rng.choice([-1.0, 1.0], 3))
+                o = p + rng.normal(0, 1, 3) * (np.abs(hi - lo).max() * rng.choice([2.0, 50.0, 1e4]))
+                rays.append(np.concatenate([o, p - o, [0.5]]))
+        rays = np.array(rays, dtype=F)
+        a, b = ref.trace_rays(rays), dev.trace_rays(rays)
+        same = (a["prim_id"] == b["prim_id"]) & (a["sub_id"] == b["sub_id"]) & (bits(a["t"]) == bits(b["t"]))
+        assert same.all(), np.flatnonzero(~same)[:10]
+        assert (a["prim_id"] >= 0).sum() > len(rays) // 10
+    finally:
+        dev.close()
+
+
 def test_progressive_rendering_and_resume_in_float64(tmp_path):
     """render_progressive on a Float64 scene: the accumulator, the state that np.savez stores and the pictures are
     double; the last picture is the one-shot picture up to the order of the sums, interrupted or not."""
