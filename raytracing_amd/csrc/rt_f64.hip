@@ -52,8 +52,9 @@ struct __align__(64) Node64 { // src/BVH.jl:5-10 (one 64-byte line: four 16-byte
 // What the walk of a tree over objects reads of a node: the box narrowed to float and the links, half a Node64.  The
 // float box decides the reference's box test wherever the rounding of its planes cannot matter (box_verdict32); where
 // it can, the walk reads the node's Node64 and decides as before.  inner node: left, right > 0, the children's ids;
-// leaf of one object (every leaf of a tree the reference builds): left = the object, right = -1; leaf of the objects at
-// positions l..r: left = l, right = -1 - r.  Tree over meshes (src/mesh.jl:250-305): a leaf of either level keeps left
+// leaf of one object (every leaf of a tree the reference builds): left = the object, right = -1 - its Leaf64::code, so
+// that the walk need not read the record's head; leaf of the objects at positions l..r: left = l, right = r with the
+// top bit set.  Tree over meshes (src/mesh.jl:250-305): a leaf of either level keeps left
 // and holds right = -1 - r.
 struct __align__(32) Node32 {
     float box[6];
@@ -66,9 +67,10 @@ struct Leaf64 {
     int32_t kind;     // the plain object's kind; for everything else (medium, tree, mesh) the object's own kind
     int32_t material;
     int32_t xf;       // transform index, -1: none
-    int32_t pad;
-    real p[12];
-    real inv[12];     // src/transform.jl:65: inv_xform, 3x4 column-major
+    int32_t code;     // what a walk must know before it reads the rest (a leaf's Node32 carries it too): bits 0-3 kind, bit 4 a
+                      // transform, bits 5-7 the kind of a medium's boundary
+    real p[12];       // a medium: its boundary's numbers, and in p[11] the medium's own (-1 / density)
+    real inv[12];     // src/transform.jl:65: inv_xform, 3x4 column-major (a medium: of the Transform around its boundary)
 };
 struct Tree64 {
     int32_t node_base, n_nodes, obj_base, n_objects, is_mesh, pad0, pad1, pad2;
@@ -506,6 +508,22 @@ __device__ Hit hit_basic(const Scene64& S, int kind, int material, const real* p
     }
     return miss();
 }
+// the distance alone, for the walk: (u, v) never decide it
+__device__ inline real hit_basic_t(int kind, const real* p, const Ray& r, real t_min, real t_max) {
+    switch (kind) {
+        case RT_SPHERE: return hit_sphere(v3(p[0], p[1], p[2]), p[3], 0, r, t_min, t_max, false).t;
+        case RT_MOVING_SPHERE: { // src/sphere.jl:24-26
+            V3 c0 = v3(p[0], p[1], p[2]), c1 = v3(p[4], p[5], p[6]);
+            V3 center = c0 + ((r.time - p[3]) / (p[7] - p[3])) * (c1 - c0);
+            return hit_sphere(center, p[8], 0, r, t_min, t_max, false).t;
+        }
+        case RT_XY_RECT: return hit_rect(2, p[0], p[1], p[2], p[3], p[4], 0, r, t_min, t_max, false).t;
+        case RT_XZ_RECT: return hit_rect(1, p[0], p[1], p[2], p[3], p[4], 0, r, t_min, t_max, false).t;
+        case RT_YZ_RECT: return hit_rect(0, p[0], p[1], p[2], p[3], p[4], 0, r, t_min, t_max, false).t;
+        case RT_BOX: return hit_box(p, 0, r, t_min, t_max, false).t;
+    }
+    return R64_INF;
+}
 // src/transform.jl:76-98
 __device__ inline V3 apply_point(const real* T, V3 v) {
     return v3(T[0] * v.x + T[3] * v.y + T[6] * v.z + T[9], T[1] * v.x + T[4] * v.y + T[7] * v.z + T[10],
@@ -638,22 +656,50 @@ __device__ inline Ray to_object_frame(const rtTransform64& T, const Ray& r) {
     return rr;
 }
 
+// hit_medium's distance from the medium's one record (its boundary's numbers and transform are in it): the same
+// operations on the same values, so the same distance
+__device__ inline real hit_medium_t(const Leaf64& L, int code, int oi, const Ray& r, real t_min, real t_max, const Ctx& c) { // src/constant_medium.jl:29-65
+    const int boundary = code >> 5;
+    Ray rr = r;
+    if (code & 16) {
+        rr.o = apply_point(L.inv, r.o);
+        rr.d = apply_vec(L.inv, r.d);
+    }
+    real t1 = hit_basic_t(boundary, L.p, rr, -R64_INF, R64_INF);
+    if (t1 == R64_INF) return R64_INF;
+    real t2 = hit_basic_t(boundary, L.p, rr, t1 + 0.0001, R64_INF);
+    if (t2 == R64_INF) return R64_INF;
+    if (t1 < t_min) t1 = t_min;
+    if (t2 > t_max) t2 = t_max;
+    if (t1 >= t2) return R64_INF;
+    if (t1 < 0.0) t1 = 0.0;
+    real ray_length = length(r.d);
+    real distance_inside_boundary = (t2 - t1) * ray_length;
+    real a, b;
+    c.draw2(PURPOSE_MEDIUM, (uint32_t)oi, a, b);
+    real hit_distance = L.p[11] * det_log(a);
+    if (hit_distance > distance_inside_boundary) return R64_INF;
+    return t1 + hit_distance / ray_length;
+}
+
 // distance of the hit of object oi (Inf: none); for a nested tree also which object inside it and with what bound
 template <bool NESTED, bool GROUPS>
-__device__ inline real hit_object_t(const Scene64& S, int oi, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp,
+// code: the object's Leaf64::code (from the leaf's node, so the record's head is not read)
+__device__ inline real hit_object_t(const Scene64& S, int oi, int code, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp,
                                     int32_t& inner, real& inner_bound) {
     const Leaf64& L = S.fused[oi];
-    if (L.kind >= RT_SPHERE && L.kind <= RT_BOX) { // a plain object, possibly inside a Transform: the distance carries over
-        if (L.xf < 0) return hit_basic(S, L.kind, L.material, L.p, r, t_min, t_max).t;
+    const int kind = code & 15;
+    if (kind >= RT_SPHERE && kind <= RT_BOX) { // a plain object, possibly inside a Transform: the distance carries over
+        if (!(code & 16)) return hit_basic_t(kind, L.p, r, t_min, t_max);
         Ray rr;
         rr.o = apply_point(L.inv, r.o);
         rr.d = apply_vec(L.inv, r.d);
         rr.time = r.time;
-        return hit_basic(S, L.kind, L.material, L.p, rr, t_min, t_max).t;
+        return hit_basic_t(kind, L.p, rr, t_min, t_max);
     }
+    if (!NESTED && kind == RT_CONSTANT_MEDIUM) return hit_medium_t(L, code, oi, r, t_min, t_max, c);
     const rtObject64& o = S.objects[oi];
     if (!NESTED) {
-        if (o.kind == RT_CONSTANT_MEDIUM) return hit_medium(S, oi, r, t_min, t_max, c).t;
         const bool wrapped = o.kind == RT_TRANSFORM && S.objects[o.child].kind == RT_BVH;
         if (GROUPS && (o.kind == RT_BVH || wrapped)) {
             Lite l;
@@ -689,13 +735,14 @@ __device__ Lite hit_tree(const Scene64& S, int tree, const Ray& r, const V3& inv
             // src/hittable.jl:21-31 over objects[left:right]
             Lite lh = lite_miss();
             real tm = t_max;
-            const bool one = node.right == -1;
-            const int first = one ? 0 : node.left, last = one ? 0 : -1 - node.right;
+            const bool one = node.right >= -256;
+            const int first = one ? 0 : node.left, last = one ? 0 : (int)((uint32_t)node.right & 0x7fffffffu);
             for (int i = first; i <= last; ++i) {
                 int oi = one ? node.left : S.tree_objects[T.obj_base + i - 1];
+                const int code = one ? -1 - node.right : S.fused[oi].code;
                 int32_t inner = -1;
                 real inner_bound = R64_INF;
-                real t = hit_object_t<NESTED, GROUPS>(S, oi, r, t_min, tm, c, stk, n, inner, inner_bound);
+                real t = hit_object_t<NESTED, GROUPS>(S, oi, code, r, t_min, tm, c, stk, n, inner, inner_bound);
                 if (t < lh.t) {
                     lh.t = t; lh.bound = tm; lh.oi = oi; lh.inner = inner; lh.inner_bound = inner_bound;
                     tm = t;
@@ -1301,6 +1348,19 @@ int check_tree(const rtSceneDesc64& D, const rtBvh64& T, bool nested, int* statu
     return deepest + 2;
 }
 
+// Leaf64::code of object oi (the description has been checked)
+int leaf_code(const rtSceneDesc64& D, int oi) {
+    const rtObject64& o = D.objects[oi];
+    if (o.kind == RT_TRANSFORM && is_basic(D.objects[o.child].kind)) return D.objects[o.child].kind | 16;
+    if (o.kind == RT_CONSTANT_MEDIUM) {
+        const rtObject64* b = &D.objects[o.child];
+        int wrapped = 0;
+        if (b->kind == RT_TRANSFORM) { wrapped = 16; b = &D.objects[b->child]; }
+        return RT_CONSTANT_MEDIUM | wrapped | (b->kind << 5);
+    }
+    return o.kind;
+}
+
 int stage_scene64(const rtSceneDesc64& D, Staged64& H, int* stack_need) {
     auto fail = [&](int st, const char* msg) { return rt_fail(st, "rt_scene_create_f64: %s", msg); };
     if (D.n_objects <= 0 || D.n_top <= 0 || D.n_buckets <= 0 || !D.objects || !D.top || !D.buckets) return fail(RT_EINVAL, "scene has no objects");
@@ -1421,8 +1481,8 @@ int stage_scene64(const rtSceneDesc64& D, Staged64& H, int* stack_need) {
             for (int a = 0; a < 6; ++a) q.box[a] = (float)n.box[a]; // to nearest: what box_verdict32's bound assumes
             q.left = n.left; q.right = n.right;
             if (n.leaf && T.kind == 0) {
-                if (n.left == n.right) { q.left = n.first; q.right = -1; }
-                else q.right = -1 - n.right;
+                if (n.left == n.right) { q.left = n.first; q.right = -1 - leaf_code(D, n.first); }
+                else q.right = (int32_t)(0x80000000u | (uint32_t)n.right);
             } else if (n.leaf) { // tree over meshes: left stays, right = -1 - r for either kind of leaf
                 q.right = -1 - n.right;
             }
@@ -1444,7 +1504,17 @@ int stage_scene64(const rtSceneDesc64& D, Staged64& H, int* stack_need) {
             L.kind = ch.kind; L.material = ch.material; L.xf = o.aux;
             memcpy(L.p, ch.p, sizeof(L.p));
             memcpy(L.inv, D.transforms[o.aux].inv_xform, sizeof(L.inv));
+        } else if (o.kind == RT_CONSTANT_MEDIUM) { // the boundary's numbers beside the medium's own (hit_medium_t)
+            const rtObject64* b = &D.objects[o.child];
+            if (b->kind == RT_TRANSFORM) {
+                L.xf = b->aux;
+                memcpy(L.inv, D.transforms[b->aux].inv_xform, sizeof(L.inv));
+                b = &D.objects[b->child];
+            }
+            memcpy(L.p, b->p, sizeof(L.p));
+            L.p[11] = o.p[0];
         }
+        L.code = leaf_code(D, i);
         H.fused.push_back(L);
     }
     H.top_pos.assign((size_t)D.n_objects, -1);
