@@ -378,30 +378,22 @@ __device__ inline Slack box_slack(const V3& inv) {
 }
 __device__ inline int box_verdict32(const Node32& q, const Ray& r, const V3& inv, const Slack& k, real t_min, real t_max) {
     const real TOL = 8.881784197001252e-16; // 2^-50
+    // The reference's three decisions `t_max <= t_min` in one: its interval only shrinks from axis to axis, so one of
+    // them holds if and only if the last one does.  (NaN distances drop out of min and max as they drop out of the
+    // reference's comparisons; a NaN beside a number needs an infinite plane or direction, and then e is Inf.)
     real lo = ((real)q.box[0] - r.o.x) * inv.x, hi = ((real)q.box[3] - r.o.x) * inv.x;
-    if (lo > hi) { real s = lo; lo = hi; hi = s; }
-    if (hi < t_max) t_max = hi;
-    if (lo > t_min) t_min = lo;
-    float e = fmaxf(fmaxf(fabsf(q.box[0]), fabsf(q.box[3])), 1.0f) * k.x;
-    real gap = t_max - t_min, tol = (real)e + TOL * (fabs(t_max) + fabs(t_min)) + 1e-300;
-    if (gap < -tol) return 0;
-    if (!(gap > tol)) return -1;
-
+    t_max = fmin(t_max, fmax(lo, hi));
+    t_min = fmax(t_min, fmin(lo, hi));
     lo = ((real)q.box[1] - r.o.y) * inv.y; hi = ((real)q.box[4] - r.o.y) * inv.y;
-    if (lo > hi) { real s = lo; lo = hi; hi = s; }
-    if (hi < t_max) t_max = hi;
-    if (lo > t_min) t_min = lo;
-    e = fmaxf(e, fmaxf(fmaxf(fabsf(q.box[1]), fabsf(q.box[4])), 1.0f) * k.y);
-    gap = t_max - t_min; tol = (real)e + TOL * (fabs(t_max) + fabs(t_min)) + 1e-300;
-    if (gap < -tol) return 0;
-    if (!(gap > tol)) return -1;
-
+    t_max = fmin(t_max, fmax(lo, hi));
+    t_min = fmax(t_min, fmin(lo, hi));
     lo = ((real)q.box[2] - r.o.z) * inv.z; hi = ((real)q.box[5] - r.o.z) * inv.z;
-    if (lo > hi) { real s = lo; lo = hi; hi = s; }
-    if (hi < t_max) t_max = hi;
-    if (lo > t_min) t_min = lo;
+    t_max = fmin(t_max, fmax(lo, hi));
+    t_min = fmax(t_min, fmin(lo, hi));
+    float e = fmaxf(fmaxf(fabsf(q.box[0]), fabsf(q.box[3])), 1.0f) * k.x;
+    e = fmaxf(e, fmaxf(fmaxf(fabsf(q.box[1]), fabsf(q.box[4])), 1.0f) * k.y);
     e = fmaxf(e, fmaxf(fmaxf(fabsf(q.box[2]), fabsf(q.box[5])), 1.0f) * k.z);
-    gap = t_max - t_min; tol = (real)e + TOL * (fabs(t_max) + fabs(t_min)) + 1e-300;
+    const real gap = t_max - t_min, tol = (real)e + TOL * (fabs(t_max) + fabs(t_min)) + 1e-300;
     if (gap < -tol) return 0;
     if (!(gap > tol)) return -1;
     return 1;
