@@ -367,33 +367,45 @@ __device__ inline V3 reciprocal(V3 d) { return v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.
 // float is off by up to 2^-150 instead: planes count as at least 1 in e, which covers that and keeps the product a normal
 // float.  NaN distances are ignored by the
 // comparisons here exactly as they are in the reference's.
-struct Slack { float x, y, z; };
-__device__ inline Slack box_slack(const V3& inv) {
-    const float least = 1.17549435e-38f;
-    Slack k;
-    k.x = fmaxf((float)(fabs(inv.x) * 2.384185791015625e-07), least);
-    k.y = fmaxf((float)(fabs(inv.y) * 2.384185791015625e-07), least);
-    k.z = fmaxf((float)(fabs(inv.z) * 2.384185791015625e-07), least);
-    return k;
+struct RayF { // what box_verdict32 takes of a ray: origin and reciprocal direction as floats, and per axis 2^-22 |1/d|
+    float ox, oy, oz, ix, iy, iz, kx, ky, kz;
+};
+__device__ inline float slack_of(real inv) { // Inf where float arithmetic on this axis says nothing (or the axis is parallel to the planes)
+    const real a = fabs(inv);
+    return (a >= 7.888609052210118e-31 && a <= 1.2676506002282294e+30) ? (float)(a * 2.384185791015625e-07) : __builtin_inff(); // 2^-100 .. 2^100
 }
-__device__ inline int box_verdict32(const Node32& q, const Ray& r, const V3& inv, const Slack& k, real t_min, real t_max) {
-    const real TOL = 8.881784197001252e-16; // 2^-50
-    // The reference's three decisions `t_max <= t_min` in one: its interval only shrinks from axis to axis, so one of
-    // them holds if and only if the last one does.  (NaN distances drop out of min and max as they drop out of the
-    // reference's comparisons; a NaN beside a number needs an infinite plane or direction, and then e is Inf.)
-    real lo = ((real)q.box[0] - r.o.x) * inv.x, hi = ((real)q.box[3] - r.o.x) * inv.x;
-    t_max = fmin(t_max, fmax(lo, hi));
-    t_min = fmax(t_min, fmin(lo, hi));
-    lo = ((real)q.box[1] - r.o.y) * inv.y; hi = ((real)q.box[4] - r.o.y) * inv.y;
-    t_max = fmin(t_max, fmax(lo, hi));
-    t_min = fmax(t_min, fmin(lo, hi));
-    lo = ((real)q.box[2] - r.o.z) * inv.z; hi = ((real)q.box[5] - r.o.z) * inv.z;
-    t_max = fmin(t_max, fmax(lo, hi));
-    t_min = fmax(t_min, fmin(lo, hi));
-    float e = fmaxf(fmaxf(fabsf(q.box[0]), fabsf(q.box[3])), 1.0f) * k.x;
-    e = fmaxf(e, fmaxf(fmaxf(fabsf(q.box[1]), fabsf(q.box[4])), 1.0f) * k.y);
-    e = fmaxf(e, fmaxf(fmaxf(fabsf(q.box[2]), fabsf(q.box[5])), 1.0f) * k.z);
-    const real gap = t_max - t_min, tol = (real)e + TOL * (fabs(t_max) + fabs(t_min)) + 1e-300;
+__device__ inline RayF ray_f32(const Ray& r, const V3& inv) {
+    RayF f;
+    f.ox = (float)r.o.x; f.oy = (float)r.o.y; f.oz = (float)r.o.z;
+    f.ix = (float)inv.x; f.iy = (float)inv.y; f.iz = (float)inv.z;
+    f.kx = slack_of(inv.x); f.ky = slack_of(inv.y); f.kz = slack_of(inv.z);
+    return f;
+}
+// The whole test in float.  A distance (b - o) * (1/d) computed from the float plane, the float origin and the float
+// reciprocal is off from the reference's (b - o) / d by at most 2^-24 (|b| + |o|) |1/d| (the two narrowings) plus four
+// roundings of 2^-24 relative; the bound of the walk narrowed to float is off by 2^-24 relative.  The reference's three
+// decisions `t_max <= t_min` are one: its interval only shrinks from axis to axis, so one of them holds if and only if
+// the last one does.  That one is certain when the two ends are further apart than
+//     e + 2^-20 (|t_max| + |t_min|) + 2^-100,   e = max over the axes of 2^-22 (max(|b|, 1) + |o|) |1/d|,
+// twice and more what the ends can be off by together (planes count as at least 1: that covers planes below the normal
+// float range, which are off by up to 2^-150 instead; 2^-100 covers products below it).  Overflow gives Inf or NaN on
+// both sides of a comparison only where the true values are beyond the float range too, and then the answer is "not
+// certain" or the order is the true one.  NaN distances drop out of min and max as they drop out of the reference's
+// comparisons; a NaN beside a number needs an infinite plane, origin or direction, and then e is Inf or NaN.
+__device__ inline int box_verdict32(const Node32& q, const RayF& f, real t_min, real t_max) {
+    float lo = (q.box[0] - f.ox) * f.ix, hi = (q.box[3] - f.ox) * f.ix;
+    float tmax = fminf((float)t_max, fmaxf(lo, hi));
+    float tmin = fmaxf((float)t_min, fminf(lo, hi));
+    lo = (q.box[1] - f.oy) * f.iy; hi = (q.box[4] - f.oy) * f.iy;
+    tmax = fminf(tmax, fmaxf(lo, hi));
+    tmin = fmaxf(tmin, fminf(lo, hi));
+    lo = (q.box[2] - f.oz) * f.iz; hi = (q.box[5] - f.oz) * f.iz;
+    tmax = fminf(tmax, fmaxf(lo, hi));
+    tmin = fmaxf(tmin, fminf(lo, hi));
+    float e = (fmaxf(fmaxf(fabsf(q.box[0]), fabsf(q.box[3])), 1.0f) + fabsf(f.ox)) * f.kx;
+    e = fmaxf(e, (fmaxf(fmaxf(fabsf(q.box[1]), fabsf(q.box[4])), 1.0f) + fabsf(f.oy)) * f.ky);
+    e = fmaxf(e, (fmaxf(fmaxf(fabsf(q.box[2]), fabsf(q.box[5])), 1.0f) + fabsf(f.oz)) * f.kz);
+    const float gap = tmax - tmin, tol = e + 9.5367431640625e-07f * (fabsf(tmax) + fabsf(tmin)) + 7.888609052210118e-31f;
     if (gap < -tol) return 0;
     if (!(gap > tol)) return -1;
     return 1;
@@ -637,7 +649,7 @@ __device__ inline Lite lite_miss() {
 // GROUPS: the scene has nested trees (BVHTree objects); a scene without them is walked by code that does not hold the
 // registers a second, inner walk needs (128 instead of 168: four waves per SIMD instead of three)
 template <bool NESTED, bool GROUPS>
-__device__ Lite hit_tree(const Scene64& S, int tree, const Ray& r, const V3& inv, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp0);
+__device__ Lite hit_tree(const Scene64& S, int tree, const Ray& r, const RayF& rf, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp0);
 
 // the ray in the frame of a Transform (src/transform.jl:105-107)
 __device__ inline Ray to_object_frame(const rtTransform64& T, const Ray& r) {
@@ -697,9 +709,9 @@ __device__ inline real hit_object_t(const Scene64& S, int oi, int code, const Ra
             Lite l;
             if (wrapped) {
                 Ray rr = to_object_frame(S.transforms[o.aux], r);
-                l = hit_tree<true, GROUPS>(S, S.n_buckets + S.objects[o.child].aux, rr, reciprocal(rr.d), t_min, t_max, c, stk, sp);
+                l = hit_tree<true, GROUPS>(S, S.n_buckets + S.objects[o.child].aux, rr, ray_f32(rr, reciprocal(rr.d)), t_min, t_max, c, stk, sp);
             } else {
-                l = hit_tree<true, GROUPS>(S, S.n_buckets + o.aux, r, reciprocal(r.d), t_min, t_max, c, stk, sp);
+                l = hit_tree<true, GROUPS>(S, S.n_buckets + o.aux, r, ray_f32(r, reciprocal(r.d)), t_min, t_max, c, stk, sp);
             }
             inner = l.oi;
             inner_bound = l.bound;
@@ -710,18 +722,17 @@ __device__ inline real hit_object_t(const Scene64& S, int oi, int code, const Ra
 }
 
 template <bool NESTED, bool GROUPS>
-__device__ Lite hit_tree(const Scene64& S, int tree, const Ray& r, const V3& inv, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp0) { // src/BVH.jl:22-53
+__device__ Lite hit_tree(const Scene64& S, int tree, const Ray& r, const RayF& rf, real t_min, real t_max, const Ctx& c, uint32_t* stk, int sp0) { // src/BVH.jl:22-53
     const Tree64 T = S.trees[tree];
     Lite closest = lite_miss();
     if (T.n_nodes == 0) return closest;
     int n = sp0;
     stk[(n++) * R64_BLOCK] = 1u;
-    const Slack slack = box_slack(inv);
     while (n > sp0) {
         const size_t at_node = (size_t)T.node_base + stk[(--n) * R64_BLOCK] - 1u;
         const Node32 node = S.nodes32[at_node];
-        int pass = box_verdict32(node, r, inv, slack, t_min, t_max);
-        if (pass < 0) pass = hit_aabb_fast(S.nodes[at_node].box, r, inv, t_min, t_max) ? 1 : 0;
+        int pass = box_verdict32(node, rf, t_min, t_max);
+        if (pass < 0) pass = hit_aabb_fast(S.nodes[at_node].box, r, reciprocal(r.d), t_min, t_max) ? 1 : 0; // (rare: the reciprocals are not kept for it)
         if (!pass) continue;
         if (node.right < 0) {
             // src/hittable.jl:21-31 over objects[left:right]
@@ -750,14 +761,13 @@ __device__ Lite hit_tree(const Scene64& S, int tree, const Ray& r, const V3& inv
 }
 
 // src/mesh.jl:115-163: the CPU walk of a tree over meshes (t_max is not narrowed)
-__device__ Lite hit_mesh_tree(const Scene64& S, int tree, const Ray& r, const V3& inv, real t_min, real t_max, uint32_t* stk) {
+__device__ Lite hit_mesh_tree(const Scene64& S, int tree, const Ray& r, const RayF& rf, real t_min, real t_max, uint32_t* stk) {
     const Tree64 T = S.trees[tree];
     Lite closest = lite_miss();
     if (T.n_nodes == 0) return closest;
     int n = 1;
     stk[0] = 1u;
     int active_mesh_index = 0;
-    const Slack slack = box_slack(inv);
     while (n > 0) {
         if (active_mesh_index == n) {
             active_mesh_index = 0;
@@ -767,8 +777,8 @@ __device__ Lite hit_mesh_tree(const Scene64& S, int tree, const Ray& r, const V3
         const size_t at_node = (size_t)T.node_base + stk[(n - 1) * R64_BLOCK] - 1u;
         const Node32 q = S.nodes32[at_node];
         n -= 1;
-        int pass = box_verdict32(q, r, inv, slack, t_min, t_max);
-        if (pass < 0) pass = hit_aabb_fast(S.nodes[at_node].box, r, inv, t_min, t_max) ? 1 : 0;
+        int pass = box_verdict32(q, rf, t_min, t_max);
+        if (pass < 0) pass = hit_aabb_fast(S.nodes[at_node].box, r, reciprocal(r.d), t_min, t_max) ? 1 : 0;
         if (!pass) continue;
         struct { int left, right; bool leaf; } node = {q.left, q.right < 0 ? -1 - q.right : q.right, q.right < 0}; // (a leaf of a tree over meshes: right = -1 - r)
         if (node.leaf) {
@@ -826,9 +836,9 @@ template <bool GROUPS>
 __device__ Lite hit_scene_lite(const Scene64& S, const Ray& r, real t_min, real t_max, const Ctx& c, uint32_t* stk) {
     Lite a = lite_miss();
     real closest_t = t_max;
-    const V3 inv = reciprocal(r.d);
+    const RayF rf = ray_f32(r, reciprocal(r.d));
     for (int b = 0; b < S.n_buckets; ++b) {
-        Lite h = S.trees[b].is_mesh ? hit_mesh_tree(S, b, r, inv, t_min, closest_t, stk) : hit_tree<false, GROUPS>(S, b, r, inv, t_min, closest_t, c, stk, 0);
+        Lite h = S.trees[b].is_mesh ? hit_mesh_tree(S, b, r, rf, t_min, closest_t, stk) : hit_tree<false, GROUPS>(S, b, r, rf, t_min, closest_t, c, stk, 0);
         if (b == 0) { a = h; continue; }
         if (a.t <= h.t) { /* keep a */ }
         else { closest_t = h.t; a = h; }
