@@ -359,14 +359,8 @@ __device__ inline bool hit_aabb_fast(const real* b, const Ray& r, const V3& inv,
 }
 __device__ inline V3 reciprocal(V3 d) { return v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
 
-// hit_aabb_fast on a box whose planes were rounded to float: 1 the reference's test passes, 0 it fails, -1 not certain
-// (take the planes in double).  A plane b read as float is off by at most 2^-24 |b|, its distance (b - o) * inv by that
-// times |inv|; slack.x/y/z hold 2^-22 |inv| (a float, rounded, at least the smallest normal float, Inf for a zero
-// direction component), so e below is more than twice what either end of the interval can be off by because of the
-// narrowing; the 2^-50 term covers the reciprocals as in hit_aabb_fast.  A plane closer to zero than the smallest normal
-// float is off by up to 2^-150 instead: planes count as at least 1 in e, which covers that and keeps the product a normal
-// float.  NaN distances are ignored by the
-// comparisons here exactly as they are in the reference's.
+// box_verdict32: the reference's box test decided on a node's float box (Node32) -- 1 it passes, 0 it fails, -1 not
+// certain (then the walk takes the planes in double through hit_aabb_fast).
 struct RayF { // what box_verdict32 takes of a ray: origin and reciprocal direction as floats, and per axis 2^-22 |1/d|
     float ox, oy, oz, ix, iy, iz, kx, ky, kz;
 };
