@@ -195,6 +195,11 @@ int rt_group_size(const rtGroup* group, int* n_devices);
 int rt_group_render(rtGroup* group, const rtCamera* camera, const float* pattern, int n, const float background[3],
                     int width, int height, int max_depth, uint64_t seed, uint32_t flags, float* out, rtStats* stats);
 int rt_group_destroy(rtGroup* group);
+/* No counterpart in the reference.  RT_OK if the RCCL library a group of several devices sums through can be loaded
+ * (librccl.so.1 from the loader's path, or the file RT_AMD_RCCL_LIB names), RT_ERCCL with the loader's message if not:
+ * what rt_group_render would answer on its first frame, without needing a GPU to ask.  The answer is kept for the life
+ * of the process. */
+int rt_rccl_available(void);
 
 /* The two halves of rt_render for spp sharding across GPUs (one process per GPU):
  * rt_render_accumulate replaces the @cuda draw_kernel launch (src/Ray_Tracing.jl:151): it WRITES to the device
@@ -206,8 +211,10 @@ int rt_render_accumulate(rtScene* scene, const rtCamera* camera, const float* pa
                          int sample_stride, const float background[3], int width, int height, int max_depth,
                          uint64_t seed, uint32_t flags, float* d_accum, void* stream);
 int rt_finalize(rtScene* scene, const float* d_accum, int n_total, int width, int height, float* d_out, void* stream);
-/* No counterpart in the reference.  rt_render_accumulate for callers that cannot allocate device memory: code under
- * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments (no flags), same result
+/* No counterpart in the reference.  rt_render_accumulate for callers that cannot allocate device memory: tight
+ * serving loops, harnesses that forbid hipMalloc, code that must leave the device's memory map untouched (the call is
+ * NOT capturable into a HIP graph: the frame loop is driven by the host, which reads a counter back and waits for the
+ * stream after every batch of bounces).  Same arguments (no flags), same result
  * bit for bit, but the path pool, the list of slots on hold, the dispenser words, the pattern copy and the per-path
  * radiance buffer live in a fixed scratch array inside the library's code object (53 MiB, held by
  * every GPU the library is loaded on until the process ends), so the call makes no hipMalloc / hipFree and creates no

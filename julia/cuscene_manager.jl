@@ -171,6 +171,7 @@ order of the groups.  `keep` holds every array the description points into; it m
 rt_scene_create has returned, which copies all of it.
 """
 function flatten(bvh::Tuple)
+    isempty(bvh) && error("librt_amd: a scene needs at least one tree with an object (draw! renders an empty world itself)")
     F = element_type(bvh[1])                        # BVHTree{F,T}: the F of render(F, ...) (main.jl:21)
     t = SceneTables(F)
     top = Int32[]                                   # the object vector of render(): the groups one after the other
@@ -197,19 +198,19 @@ function CuSceneManager(bvh::Tuple; device::Integer = 0, devices::Union{Nothing,
     desc, keep = flatten(bvh)
     F = element_type(bvh[1])
     handle = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve keep begin
+    list = devices === nothing ? Cint[] : Vector{Cint}(devices)     # rooted below: ccall gets a raw pointer into it
+    GC.@preserve keep list begin
+        members = isempty(list) ? Ptr{Cint}(C_NULL) : pointer(list)
         if F === Float64 && devices === nothing
             check(ccall((:rt_scene_create_f64, librt), Cint, (Ref{RtSceneDesc64}, Cint, Ref{Ptr{Cvoid}}), desc, device, handle))
         elseif F === Float64
-            list = Cint.(devices)
             check(ccall((:rt_group_create_f64, librt), Cint, (Ref{RtSceneDesc64}, Ptr{Cint}, Cint, Ref{Ptr{Cvoid}}), desc,
-                        isempty(list) ? C_NULL : pointer(list), length(list), handle))
+                        members, length(list), handle))
         elseif devices === nothing
             check(ccall((:rt_scene_create, librt), Cint, (Ref{RtSceneDesc}, Cint, Ref{Ptr{Cvoid}}), desc, device, handle))
         else
-            list = Cint.(devices)
             check(ccall((:rt_group_create, librt), Cint, (Ref{RtSceneDesc}, Ptr{Cint}, Cint, Ref{Ptr{Cvoid}}), desc,
-                        isempty(list) ? C_NULL : pointer(list), length(list), handle))
+                        members, length(list), handle))
         end
     end
     scene = CuSceneManager(handle[], devices === nothing ? Int(device) : -1, F)

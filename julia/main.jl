@@ -15,7 +15,10 @@
 #         img = Array(d_img)
 #
 # `kwargs...` lets render(:cu_cover2; gpu = true, spp = 1000, seed = 7, devices = [0, 1, 2, 3]) reach the device path's
-# own keywords (seed, devices, max_depth); everything else about the call is unchanged, so this is a drop-in.
+# own keywords (seed, devices, max_depth); everything else about the call is unchanged, so this is a drop-in.  The
+# collection also carries what render(key::Symbol; ...) merged in and this method does not name -- `spp` of the
+# README's own render(:cornell_box; spp=10000, gpu=true) -- so draw!(::DeviceImage, ...) ends its keyword list with a
+# sink (`ignored...`) and drops them, as this method's unused `kwargs...` always did.
 #
 # Written out, the patched method (the reference's signature, main.jl:21-29):
 

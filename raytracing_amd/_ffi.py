@@ -201,6 +201,7 @@ SYMBOLS = {
     "rt_group_render": (C.c_int, [C.c_void_p, C.POINTER(rtCamera), c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int,
                                   C.c_uint64, C.c_uint32, c_f32p, C.POINTER(rtStats)]),
     "rt_group_destroy": (C.c_int, [C.c_void_p]),
+    "rt_rccl_available": (C.c_int, []),
     "rt_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "rt_get_counters": (C.c_int, [C.c_void_p, C.POINTER(rtStats)]),
     "rt_trace_rays": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.c_float, C.c_float, C.c_uint64, c_i32p, c_i32p,

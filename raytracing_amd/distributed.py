@@ -7,7 +7,7 @@ over pattern columns, which is associative up to FP32 rounding).
 
 sharded_frame() is that frame, written once: bench.py runs it with a DeviceScene and dist.all_reduce over RCCL, the CPU
 test (tests/test_dist_gloo.py) with a stand-in scene and gloo.  (A single process that drives several GPUs itself uses
-rt_render_multi of the C ABI instead, see DeviceGroup in render.py.)
+rt_group_create / rt_group_render of the C ABI instead, see DeviceGroup in render.py.)
 """
 import numpy as np
 

@@ -258,9 +258,13 @@ def test_group_of_devices_in_one_process(scenes, monkeypatch):
     try:
         assert three.n_devices == 3
         img, _ = three.render(cam, pat, bg, W, H)
+        # the members' host threads and the group's events outlive a frame: a larger frame (the accumulators grow),
+        # then the first one again
+        larger, _ = three.render(cam, pat, bg, 96, 80)
         again, _ = three.render(cam, pat, bg, W, H)
     finally:
         three.close()
+    np.testing.assert_allclose(larger, dev.render(cam, pat, bg, 96, 80)[0], rtol=2e-6, atol=1e-7)
     np.testing.assert_array_equal(bits(img), bits(again))
     np.testing.assert_allclose(img, full, rtol=2e-6, atol=1e-7)
     stream = torch.cuda.current_stream().cuda_stream
@@ -282,6 +286,38 @@ def test_group_of_devices_in_one_process(scenes, monkeypatch):
         every.close()
     with pytest.raises(ffi.RtError):
         rt.DeviceGroup(world, devices=[torch.cuda.device_count()])
+
+
+def test_group_render_without_rccl_is_rt_erccl_and_the_peer_sum_still_works():
+    """rt_group_render on a host whose RCCL library cannot be loaded (RT_AMD_RCCL_LIB names a file that is not there):
+    the frame that needs the collective fails with RT_ERCCL and the loader's message, nothing crashes, and the same
+    group renders through peer copies (RT_AMD_REDUCE=peer).  In a child process: the library asks the loader once."""
+    import subprocess
+    code = """
+import os, numpy as np
+import raytracing_amd as rt
+from raytracing_amd import _ffi as ffi
+world, kw = rt.get_scene("cornell_box", spp=4)
+g = rt.DeviceGroup(world, devices=[0])
+try:
+    g.render(kw["camera"], kw["pattern"], kw["background"], 32, 32)
+    print("no error")
+except ffi.RtError as e:
+    print("error:", e)
+os.environ["RT_AMD_REDUCE"] = "peer"
+os.environ.pop("RT_AMD_FORCE_RCCL")
+img, _ = g.render(kw["camera"], kw["pattern"], kw["background"], 32, 32)
+one = rt.DeviceScene(world)
+want, _ = one.render(kw["camera"], kw["pattern"], kw["background"], 32, 32)
+print("peer ok" if np.array_equal(img, want) else "peer differs")
+g.close(); one.close()
+"""
+    env = dict(os.environ, RT_AMD_FORCE_RCCL="1", RT_AMD_RCCL_LIB="/nonexistent/librccl.so.1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=os.path.dirname(HERE), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0].startswith("error: librt_amd: status -6") and "/nonexistent/librccl.so.1 could not be loaded" in lines[0], lines
+    assert "unknown error" not in lines[0] and lines[1] == "peer ok", lines
 
 
 @pytest.mark.parametrize("name", ["cornell_smoke_box", "cu_cover2", "teapot"])

@@ -204,3 +204,50 @@ def test_group_entry_points_without_a_device():
         assert L.rt_group_create(C.byref(desc), None, 0, C.byref(handle)) == -2       # RT_ENODEV
         assert b"no HIP device" in L.rt_last_error() and not handle
     del keep
+
+
+def _child(code, **env):
+    """runs `code` in a fresh interpreter (the library caches what it learns about RCCL for the life of a process)"""
+    import subprocess
+    import sys
+    e = dict(os.environ, **env)
+    return subprocess.run([sys.executable, "-c", code], env=e, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                          capture_output=True, text=True, timeout=300)
+
+
+def test_a_missing_rccl_library_is_rt_erccl_with_the_loaders_message():
+    """A group of several devices sums through librccl, loaded at run time; a host without it must get RT_ERCCL and the
+    loader's reason (not a crash: dlerror() hands its message out once).  RT_AMD_RCCL_LIB names the file to load, so a
+    name that does not exist is a host without the library.  No GPU is needed to ask (rt_rccl_available)."""
+    code = ("from raytracing_amd import _ffi as f\nL = f.lib()\nst = L.rt_rccl_available()\n"
+            "print(st, L.rt_last_error().decode())\nst2 = L.rt_rccl_available()\nprint(st2, L.rt_last_error().decode())")
+    r = _child(code, RT_AMD_RCCL_LIB="/nonexistent/librccl.so.1")
+    assert r.returncode == 0, r.stderr
+    first, second = r.stdout.strip().splitlines()
+    assert first.startswith("-6 ") and "/nonexistent/librccl.so.1 could not be loaded: " in first, first
+    assert "No such file" in first or "cannot open" in first, first        # the loader's own words, not "unknown error"
+    assert second == first                                                 # the answer is kept, and asking again does not crash
+    # with the library where the image has it the answer is RT_OK (skipped where there is no ROCm installation)
+    if os.path.exists("/opt/rocm/lib/librccl.so.1"):
+        r = _child(code)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.strip().splitlines()[0].startswith("0 "), r.stdout
+
+
+def test_a_group_of_more_devices_than_the_host_has_fails_cleanly():
+    """a duplicate-free list that names a device the host does not have: RT_EINVAL with the range (RT_ENODEV without any
+    GPU), no handle, and the library goes on working"""
+    L = ffi.lib()
+    world, _ = rt.get_scene("cornell_box", spp=1)
+    desc, keep = flatten_scene(world, rt.build_bvh_scene(rt.SceneManager(world)))
+    count = C.c_int(0)
+    assert L.rt_device_count(C.byref(count)) == 0
+    want = np.arange(count.value + 1, dtype=np.int32)                      # 0 .. visible: one too many, none twice
+    handle = C.c_void_p()
+    st = L.rt_group_create(C.byref(desc), ffi.iptr(want), len(want), C.byref(handle))
+    if count.value == 0:
+        assert st == -2 and not handle
+    else:
+        assert st == -1 and b"out of range" in L.rt_last_error() and not handle
+    assert L.rt_abi_version() == 1
+    del keep

@@ -223,3 +223,133 @@ def test_overlay_applies_to_the_reference(tmp_path):
         assert m, struct
         have = re.findall(r"^\s+(\w+)::", m.group(1), flags=re.M)
         assert have[:len(names)] == names, (struct, have)
+
+
+# ---- the call path: which keywords reach draw!(::DeviceImage, ...) and whether its methods take them ----------------
+
+def julia_signature(text, head):
+    """The keyword part of the method whose definition starts with `head`: (named keywords, name of the slurp or None)"""
+    a = text.index(head)
+    depth, i = 0, a + head.index("(")        # the opening parenthesis of the argument list
+    for j in range(i, len(text)):
+        depth += text[j] == "("
+        depth -= text[j] == ")"
+        if depth == 0:
+            break
+    args = text[i + 1:j]
+    if ";" not in args:
+        return set(), None
+    kw = args.split(";", 1)[1]
+    parts, depth, cur = [], 0, ""
+    for ch in kw:
+        if ch == "," and depth == 0:
+            parts.append(cur.strip()); cur = ""
+        else:
+            depth += ch in "({["
+            depth -= ch in ")}]"
+            cur += ch
+    if cur.strip():
+        parts.append(cur.strip())
+    named, slurp = set(), None
+    for p in parts:
+        if p.endswith("..."):
+            slurp = p[:-3]
+        else:
+            named.add(re.match(r"\w+", p).group(0))
+    return named, slurp
+
+
+def call_keywords(call):
+    """names of the keywords written in a Julia call `render(...; a = 1, b = 2)`"""
+    return set(re.findall(r"(\w+)\s*=", call.split(";", 1)[1])) if ";" in call else set()
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "src")), reason="the reference checkout is not on this machine")
+def test_documented_render_calls_reach_draw_with_keywords_it_takes(tmp_path):
+    """render(:cornell_box; spp = 10000, gpu = true) is the reference's own GPU example (README.md:79).  Its keywords
+    travel: render(F, key; gpu, kwargs...) (main.jl:90-94) hands all of them to the scene function (which takes
+    `kwargs...`), merges them over the scene's own and calls render(F, world; ...) (main.jl:21-29), which names six and
+    collects the rest in `kwargs...`; the patched gpu branch passes that collection on to draw!(::DeviceImage, ...).
+    Every keyword that can arrive there -- `spp` among them -- must be taken by the method, or the call is a MethodError.
+    Walked here on the overlay applied to a copy of the reference, for the README's calls and INTEGRATION.md's."""
+    work = tmp_path / "ref"
+    shutil.copytree(REFERENCE, work)
+    for d, _, files in os.walk(work):
+        os.chmod(d, 0o755)
+        for f in files:
+            os.chmod(os.path.join(d, f), 0o644)
+    subprocess.check_call([sys.executable, os.path.join(JULIA, "apply_overlay.py"), str(work)])
+    main = open(work / "main.jl").read()
+    device = open(work / "src" / "Ray_Tracing_device.jl").read()
+
+    # the documented calls
+    readme = open(os.path.join(REFERENCE, "README.md")).read()
+    integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    calls = re.findall(r"render\(:\w+[^)\n]*\)", readme) + re.findall(r"render\(:\w+[^)\n]*\)", integration)
+    assert any("spp=10000, gpu=true" in c for c in calls) and any("devices" in c for c in calls) and any("seed" in c for c in calls), calls
+
+    # render(F, key::Symbol; gpu, kwargs...): what it names, what it passes on
+    by_key, slurp = julia_signature(main, "function render(::Type{F}, key::Symbol")
+    assert by_key == {"gpu"} and slurp == "kwargs"
+    assert "render(F, world; kwargs..., gpu=gpu)" in main and "kwargs = merge(scene_kwargs, kwargs)" in main
+    scenes = open(work / "scenes.jl").read()
+    scene_kwargs = set(re.findall(r"(\w+)=\w+", re.search(r"return world, \((.*?)\)", scenes).group(1)))
+    assert scene_kwargs == {"width", "height", "camera", "background", "pattern"}
+    for f in os.listdir(work / "samples"):                      # the scene functions take whatever they are handed
+        head = re.search(r"^scenes\[:\w+\] = \(;(.*?)\) -> begin", open(work / "samples" / f).read(), flags=re.M).group(1)
+        assert "kwargs..." in head, f
+
+    # render(F, world::Vector; ...): what it names; the rest is `kwargs...`, which the gpu branch forwards
+    by_world, slurp = julia_signature(main, "function render(::Type{F}, world::Vector{<:Hittable}")
+    assert by_world == {"width", "height", "camera", "background", "pattern", "gpu"} and slurp == "kwargs"
+    forward = re.search(r"draw!\(d_img, world, camera;([^\n]*)\)", main).group(1)
+    assert "kwargs..." in forward
+    always = set(re.findall(r"(\w+)\s*=", forward))              # background, pattern
+    assert always == {"background", "pattern"}
+
+    methods = []
+    for F in ("Float32", "Float64"):
+        named, sink = julia_signature(device, "function draw!(img::DeviceImage{%s}, world::SceneManager, camera::Camera{%s}" % (F, F))
+        assert {"background", "pattern", "seed", "devices", "max_depth"} <= named, named
+        methods.append((F, named, sink))
+
+    for call in calls:
+        arriving = (call_keywords(call) | scene_kwargs) - by_key          # after the merge of main.jl:92
+        at_draw = (arriving - by_world) | always                           # what render(F, world) does not name + what it passes itself
+        for F, named, sink in methods:
+            missing = at_draw - named
+            assert not missing or sink is not None, (call, F, "draw! has no keyword or sink for", missing)
+    # ... and the README's GPU example does carry a keyword draw! does not name, so the sink is what makes it work
+    named, sink = methods[0][1], methods[0][2]
+    assert "spp" not in named and sink is not None
+
+
+def test_pointers_passed_to_ccall_are_rooted():
+    """A `pointer(x)` handed to ccall keeps nothing alive: every array whose raw pointer crosses the boundary in
+    CuSceneManager / draw! must be named in the GC.@preserve that encloses the call."""
+    for name in ("cuscene_manager.jl", "Ray_Tracing.jl"):
+        text = julia_sources()[name]
+        for m in re.finditer(r"GC\.@preserve ([^\n]*?) begin\n(.*?)\n    end", text, flags=re.S):
+            rooted = set(m.group(1).split())
+            for used in re.findall(r"pointer\((\w+)\)", m.group(2)):
+                assert used in rooted, (name, used, rooted)
+    text = julia_sources()["cuscene_manager.jl"]
+    body = text[text.index("function CuSceneManager(bvh::Tuple"):]
+    body = body[:body.index("\nend\n")]
+    assert "pointer(list)" in body and re.search(r"GC\.@preserve keep list begin", body)
+    assert body.index("GC.@preserve") < body.index("pointer(list)")
+
+
+def test_an_empty_world_is_rendered_by_the_glue():
+    """build_bvh of an empty group is a tree without nodes, which is never hit (src/scene_manager.jl:25-29,
+    src/BVH.jl:23-25); the library wants objects in every tree, so draw! leaves such trees out and paints the background
+    itself when nothing is left -- before anything indexes bvh[1]."""
+    text = julia_sources()["Ray_Tracing.jl"]
+    for F in ("Float32", "Float64"):
+        body = text[text.index("function draw!(img::DeviceImage{%s}" % F):]
+        body = body[:body.index("\nend\n")]
+        a, b, c = body.index("nonempty_trees(build_bvh(world))"), body.index("isempty(bvh) && return fill_background!"), body.index("CuSceneManager(bvh")
+        assert a < b < c
+    assert "nonempty_trees(bvh::Tuple) = filter(tree -> !isempty(tree.nodes), bvh)" in text
+    flat = julia_sources()["cuscene_manager.jl"]
+    assert flat.index("isempty(bvh) && error(") < flat.index("element_type(bvh[1])")
