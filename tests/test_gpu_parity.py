@@ -12,7 +12,7 @@ import pytest
 import oracle_ffi as O
 import raytracing_amd as rt
 from raytracing_amd import _ffi as ffi
-from conftest import SCENES
+from conftest import SCENES, blocks_showing_the_tall_box_front, cornell_box_of_meshes
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -95,6 +95,26 @@ def test_paths_and_image_vs_oracle(name, scenes):
     # check (3): the image is not merely within an RMSE, it is identical (same paths, same summation order)
     np.testing.assert_array_equal(bits(img), bits(want))
     assert st.paths == W * H * 8
+
+
+def test_cornell_box_of_meshes_vs_oracle():
+    """one mesh of 36 triangles with four materials picked per triangle (the teapot has one): ids, t, normals, uv and
+    the image bit for bit"""
+    world, kw = cornell_box_of_meshes()
+    cam, pat, bg = kw["camera"], kw["pattern"], kw["background"]
+    dev, ref = rt.DeviceScene(world), O.OracleScene(world)
+    try:
+        rays = O.primary_rays(cam, kw["width"], kw["height"], 96, 96, time=0.5)
+        a, b = ref.trace_rays(rays), dev.trace_rays(rays)
+        for k in ("prim_id", "sub_id", "front"):
+            np.testing.assert_array_equal(a[k], b[k])
+        for k in ("t", "normal", "uv"):
+            np.testing.assert_array_equal(bits(a[k]), bits(b[k]))
+        assert len(set(a["sub_id"][a["prim_id"] >= 0])) >= 20          # (sub_id = the triangle: most of the 36 are seen)
+        img, _ = dev.render(cam, pat, bg, 80, 80)
+        np.testing.assert_array_equal(bits(img), bits(ref.render(cam, pat, bg, 80, 80)))
+    finally:
+        dev.close()
 
 
 def test_edge_cases(scenes, monkeypatch):
@@ -550,6 +570,7 @@ def test_full_size_cu_cover2_against_oracle_and_properties(scenes):
 
 
 @pytest.mark.parametrize("name,key,spp,tol", [("cornell_box", "cornell_box_10000", 2000, 0.012),
+                                              ("cornell_box_of_meshes", "cornell_box_10000", 2000, 0.012),
                                               ("cornell_smoke_box", "cornell_smoke_box_10000", 1000, 0.012)])
 def test_converged_image_against_reference_gallery(name, key, spp, tol, scene_cache):
     """The two deterministic scenes at full resolution against statistics of the reference's own rendered PNGs
@@ -557,7 +578,13 @@ def test_converged_image_against_reference_gallery(name, key, spp, tol, scene_ca
     Stated RMSE bound: 0.012 on 16x16 (24x24) block means, about twice the 1000-vs-10000 spp noise floor (0.0053)
     measured between the reference's own two Cornell images."""
     stats = json.load(open(os.path.join(HERE, "golden", "gallery_stats.json")))[key]
-    world, kw = rt.get_scene(name, spp=spp)
+    if name == "cornell_box_of_meshes":
+        # the Cornell box built from triangles: the same picture, so the reference's own picture pins the triangle test
+        # (src/triangle.jl:73-121) and the mesh tree (src/mesh.jl:115-163), which no picture of the gallery shows as such
+        world, _ = cornell_box_of_meshes()
+        _, kw = rt.get_scene("cornell_box", spp=spp)
+    else:
+        world, kw = rt.get_scene(name, spp=spp)
     dev = rt.DeviceScene(world)
     try:
         img, st = dev.render(kw["camera"], kw["pattern"], kw["background"], kw["width"], kw["height"])
@@ -570,9 +597,23 @@ def test_converged_image_against_reference_gallery(name, key, spp, tol, scene_ca
     gh, gw = g.shape[0] // blk, g.shape[1] // blk
     mine = g[:gh * blk, :gw * blk].reshape(gh, blk, gw, blk, 3).mean(axis=(1, 3))
     want = np.array(stats["block_means_gamma"])
-    rmse = np.sqrt(((mine - want) ** 2).mean(axis=(0, 1)))
+    keep = np.ones((gh, gw), bool)
+    if name == "cornell_box_of_meshes":
+        # the one face on which triangles and rectangles differ in the reference's own arithmetic is left out
+        probe = rt.DeviceScene(world)
+        try:
+            keep = ~blocks_showing_the_tall_box_front(probe.trace_rays, kw, blk)
+        finally:
+            probe.close()
+        assert 0.02 < (~keep).mean() < 0.15, (~keep).mean()      # (the face is a tenth of the picture)
+    rmse = np.sqrt(((mine - want)[keep] ** 2).mean(axis=0))
     assert (rmse < tol).all(), rmse
-    np.testing.assert_allclose((g ** 2).mean(axis=(0, 1)), stats["linear_mean"], atol=0.004)
+    level = (mine ** 2)[keep].mean(axis=0)          # (mean of squared block means: the same statistic on both sides)
+    level_want = (want ** 2)[keep].mean(axis=0)
+    np.testing.assert_allclose(level, level_want, atol=0.004)
+    if name != "cornell_box_of_meshes":
+        np.testing.assert_allclose((g ** 2).mean(axis=(0, 1)), stats["linear_mean"], atol=0.004)
+    print(name, "rmse", rmse.round(4), "linear mean", np.round(level, 4), "reference", np.round(level_want, 4))
     row = g[g.shape[0] // 2].sum(axis=1)
     assert abs(int(np.argmax(row > 0.02)) - stats["black_frame_px"]) <= 1
 
