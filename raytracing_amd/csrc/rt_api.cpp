@@ -105,6 +105,7 @@ int upload_nodes(rtScene* s) {
     s->dev.n_pairs = H.pairs_per_layout;
     // (and when a record's byte offset fits 32 bits: 16 layouts of 32-byte records)
     s->dev.use_pairs = (H.pairs_per_layout && H.pairs_per_layout < (1u << 23) && depth <= RT_PAIR_STACK && !std::getenv("RT_AMD_NO_PAIRS")) ? 1u : 0u;
+    s->dev.pair_depth = depth;
     s->dev.nodes = s->d_nodes;
     s->dev.n_nodes = H.nodes_per_layout;
     s->dev.far_set = H.n_sets == 2 ? 8u * H.nodes_per_layout : 0u;
@@ -180,6 +181,7 @@ int fill_params(const float background[3], int width, int height, int max_depth,
     P->blocked_threshold = (uint32_t)env_int("RT_AMD_BLOCKED_THRESHOLD", 20);
     P->fetch_threshold = (uint32_t)env_int("RT_AMD_FETCH_THRESHOLD", 28);
     P->step_dropout = (uint32_t)env_int("RT_AMD_STEP_DROPOUT", 12);
+    P->count_mode = (uint32_t)env_int("RT_AMD_COUNT_MODE", 0);
     P->regroup = std::getenv("RT_AMD_NO_REGROUP") ? 0u : 1u;
     if (!std::getenv("RT_AMD_NO_BIN")) P->regroup |= 2u;
     return RT_OK;
@@ -260,6 +262,19 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     s->dev.first_group_base = H.bucket_base.empty() ? 0u : H.bucket_base[0];
     s->dev.nested = H.nested ? 1u : 0u;
     s->dev.textured = H.textured ? 1u : 0u;
+    s->dev.classes = 0u;
+    for (size_t k = 0; k + 2 < H.prims.size(); k += 3) {
+        const uint32_t head = H.prims[k].x, kind = head & 15u;
+        if (head & DP_MEDIUM_FLAG) continue; // a medium's boundary is tested by the shade kernel, not by the walk
+        if (kind == DP_SPHERE) s->dev.classes |= RT_CL_SPHERE;
+        else if (kind == DP_MOVING_SPHERE) s->dev.classes |= RT_CL_SPHERE | RT_CL_MOVING;
+        else if (kind >= DP_XY_RECT && kind <= DP_YZ_RECT) s->dev.classes |= RT_CL_RECT;
+        else if (kind == DP_BOX) s->dev.classes |= RT_CL_BOX;
+        else if (kind == DP_TRIANGLE) s->dev.classes |= RT_CL_TRI;
+        else s->dev.classes |= RT_CL_ALL; // (a nested tree: its kernel variant carries every class)
+        if (kind != DP_TRIANGLE && (head >> 8)) s->dev.classes |= RT_CL_XFORM;
+    }
+    if (std::getenv("RT_AMD_ALL_CLASSES")) s->dev.classes = RT_CL_ALL; // the general kernel whatever the scene holds (measurements, tests)
     *out = s;
     return RT_OK;
 }

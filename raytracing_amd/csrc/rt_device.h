@@ -48,6 +48,16 @@ enum DevPrimKind {
     DP_TRIANGLE = 7,
     DP_INSTANCE = 8
 };
+// Classes of surface primitives a scene holds (DevScene::classes): rt_extend_kernel is compiled once per set of classes
+// that occurs in practice, so that a scene of spheres carries no rectangle or triangle code (registers, instruction
+// cache) through its walk.
+#define RT_CL_SPHERE 1u  // spheres
+#define RT_CL_MOVING 2u  // moving spheres (centre from the ray's time)
+#define RT_CL_RECT 4u    // the three rectangle kinds
+#define RT_CL_BOX 8u     // boxes (six rectangle tests)
+#define RT_CL_TRI 16u    // triangles
+#define RT_CL_XFORM 32u  // a primitive sits in a Transform (ray taken into its frame first)
+#define RT_CL_ALL 63u
 #define DP_MEDIUM_FLAG 16u
 #define DP_TYPE_MASK 0xE0u // primitive head bits 5-7: material type of the primitive (1..5)
 
@@ -91,6 +101,8 @@ struct DevScene {
     uint32_t n_media;      // entries in `media`
     uint32_t n_buckets;    // entries in `bucket_base`
     uint32_t first_group_base; // bucket_base[0]: a rank at or above it belongs to the first type group
+    uint32_t pair_depth;   // deepest leaf of the tree of surfaces (entries a lane's stack needs in the walk over pair nodes)
+    uint32_t classes;      // RT_CL_* of the surface primitives (the trees' leaves; media boundaries are not among them)
 };
 
 #endif

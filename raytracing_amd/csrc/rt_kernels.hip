@@ -9,6 +9,7 @@
 // culls, uses reciprocal multiplication, and it is widened so that it never rejects a box the exact test accepts;
 // what the reference's own box tests cull on top of that is taken away again, exactly (ref_reaches).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "rt_device.h"
@@ -260,32 +261,35 @@ __device__ __forceinline__ float triangle_t(const float* g, f3 o, f3 d, float t_
 // run one copy of the arithmetic per kind: spheres and moving spheres share sphere_t, the three rectangle kinds and
 // the six sides of a box share rect_t (ray components and bounds are selected per lane).
 // Tinv: the inverse matrix of the Transform around the primitive (used when field != 0)
+// CL: the classes of primitives the scene holds (RT_CL_*); the code of the others is left out.
+template <uint32_t CL = RT_CL_ALL>
 __device__ __forceinline__ float surface_t(const float* Tinv, uint32_t kind, uint32_t field, const float* g, f3 o, f3 d,
                                            float time, float t_min, float t_max, uint32_t& side, uint32_t& xf) {
     side = 0;
-    if (kind == DP_TRIANGLE) {
+    if ((CL & RT_CL_TRI) && (CL == RT_CL_TRI || kind == DP_TRIANGLE)) {
         f3 nrm;
         float u, v;
         return triangle_t(g, o, d, t_min, t_max, nrm, u, v);
     }
     f3 ro = o, rd = d;
-    if (field) { // Transform: src/transform.jl:104-105
+    if ((CL & RT_CL_XFORM) && field) { // Transform: src/transform.jl:104-105
         ro = apply_point(Tinv, o);
         rd = apply_vec(Tinv, d);
         xf = field;
     }
-    if (kind <= DP_MOVING_SPHERE) {
+    if ((CL & RT_CL_SPHERE) && (!(CL & (RT_CL_RECT | RT_CL_BOX)) || kind <= DP_MOVING_SPHERE)) {
         f3 center = mk3(g[0], g[1], g[2]);
         float radius = g[3];
-        if (kind == DP_MOVING_SPHERE) { // src/sphere.jl:24-26
+        if ((CL & RT_CL_MOVING) && kind == DP_MOVING_SPHERE) { // src/sphere.jl:24-26
             f3 c1 = mk3(g[4], g[5], g[6]);
             center = center + ((time - g[3]) / (g[7] - g[3])) * (c1 - center);
             radius = g[8];
         }
         return sphere_t(center, radius, ro, rd, t_min, t_max);
     }
+    if (!(CL & (RT_CL_RECT | RT_CL_BOX))) return INF;
     // rectangles (src/aarect.jl:49-95) and boxes (src/box.jl:9-24,43-83: front, back, top, bottom, right, left; strict <)
-    const bool isbox = kind == DP_BOX;
+    const bool isbox = (CL & RT_CL_BOX) && (!(CL & RT_CL_RECT) || kind == DP_BOX);
     const uint32_t axis = isbox ? 2u : (kind == DP_XY_RECT ? 2u : (kind == DP_XZ_RECT ? 1u : 0u)); // constant axis
     float ok = axis == 2u ? ro.z : (axis == 1u ? ro.y : ro.x), dk = axis == 2u ? rd.z : (axis == 1u ? rd.y : rd.x);
     float oa = axis == 0u ? ro.y : ro.x, da = axis == 0u ? rd.y : rd.x;
@@ -778,13 +782,13 @@ __device__ __forceinline__ void walker_step(Walker& W, const DevScene& S, Counte
 
 // One surface leaf for the ray (o, d) of the frame being walked.  A nested tree is entered (returns true, with the
 // new frame in `W`-style arguments handled by the caller); any other primitive is tested against `best`.
-template <bool FLOOR>
+template <bool FLOOR, uint32_t CL = RT_CL_ALL>
 __device__ __forceinline__ void surface_leaf(const float* Tinv, uint32_t prim, const uint4& head, const Geom& G, f3 o, f3 d,
                                              float time, float t_min, float& t_max, uint32_t inst_rank, uint32_t inst_xf,
                                              Closest& best, float floor_t, uint32_t floor_rank) {
     uint32_t kind = head.x & 15u;
     uint32_t side = 0, xf = inst_xf;
-    float t = surface_t(Tinv, kind, kind == DP_TRIANGLE ? 0u : head.x >> 8, G.g, o, d, time, t_min, t_max, side, xf);
+    float t = surface_t<CL>(Tinv, kind, kind == DP_TRIANGLE ? 0u : head.x >> 8, G.g, o, d, time, t_min, t_max, side, xf);
     if (FLOOR) consider(best, t_max, t, prim, side | (xf << 3) | ((head.x & DP_TYPE_MASK) << 24), head.z + inst_rank, floor_t, floor_rank);
     else consider(best, t_max, t, prim, side | (xf << 3) | ((head.x & DP_TYPE_MASK) << 24), head.z + inst_rank);
 }
@@ -1486,7 +1490,11 @@ __device__ __forceinline__ void camera_ray(const RtCameraDev& cam, const float* 
 #define DEPTH_COLUMN_MASK 0xFFFFFFu
 #define DEPTH_HAS_COLOR 0x40000000u
 #define DEPTH_HOLD 0x80000000u       // the slot's hit is being settled (rt_redo_kernel): rt_extend_kernel leaves the slot alone
-#define QP(pool, plane, slot) (pool).q[(size_t)(plane) * (pool).n_slots + (slot)]
+// Index of a slot's entry in a plane of a pool of n slots.  Planes, not one 64-byte record per slot: rt_extend_kernel
+// reads two planes and writes one, and a record per slot makes it pull the whole record through the caches (measured:
+// extend +3 %, shade +4 %, the frame 1497 -> 1444 Mpaths/s).
+#define QPI(n, plane, slot) ((size_t)(plane) * (n) + (slot))
+#define QP(pool, plane, slot) (pool).q[QPI((pool).n_slots, plane, slot)]
 #define HIT_MISS 6u
 #define HIT_WAIT 7u                  // shade kernel: the slot waits for rt_redo_kernel, nothing to shade yet
 #define RANK_SETTLED 0x80000000u     // bit of the rank word of a hit record: rt_redo_kernel has settled the hit
@@ -1566,8 +1574,12 @@ __global__ void __launch_bounds__(256) rt_init_kernel(RtCameraDev cam, const flo
 // trees (Transform{BVHTree}); without them the state for the outer ray is not carried.
 #define LEAF_QUEUE 3u
 #define PAIR_LEAVES 3u // leaves a lane can have waiting in the walk over pair nodes (a step adds up to two)
-template <bool COUNT, bool NESTED, bool PAIRS>
-__global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevScene S, RtRenderParams P, PathPool pool, uint32_t* __restrict__ head,
+// CL: the classes of surface primitives the scene holds (RT_CL_*; the leaf block carries only their code).  BLOCKS:
+// workgroups per CU the kernel is compiled for (registers per lane = 512 / BLOCKS, rounded down to a multiple of 8).
+// STACK: entries of a lane's stack in the walk over pair nodes (the tree must be no deeper): with 16 instead of
+// RT_PAIR_STACK the two stacks take 19 KB of LDS per workgroup and eight workgroups fit a CU instead of six.
+template <bool COUNT, bool NESTED, bool PAIRS, uint32_t CL = RT_CL_ALL, int BLOCKS = (NESTED ? 4 : 6), uint32_t STACK = RT_PAIR_STACK>
+__global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRenderParams P, PathPool pool, uint32_t* __restrict__ head,
                                                         unsigned long long* __restrict__ counters) {
     const uint32_t lane = threadIdx.x & 63u;
     const float t_min = 0.001f;
@@ -1594,7 +1606,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
     // box that is missed).  `node` is the record to read next, 0xFFFFFFFF (= `end`) when the walk is over.  The leaves
     // found wait on a second small stack in LDS (a step can find two): in which order a lane's leaves are tested does
     // not change its closest hit.  Both stacks take their stores unconditionally at the top; only the counts say what stays.
-    __shared__ uint32_t pair_stack[PAIRS ? RT_PAIR_STACK : 1u][256];
+    __shared__ uint32_t pair_stack[PAIRS ? STACK : 1u][256];
     __shared__ uint32_t leaf_stack[PAIRS ? PAIR_LEAVES : 1u][256];
     uint32_t sp = 0;
     Closest best = {INF, 0xFFFFFFFFu, 0u, 0u};
@@ -1692,7 +1704,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
         const uint32_t n_blocked = (uint32_t)__popcll(__ballot(wl && !ws));
         if (nl >= P.leaf_threshold || n_blocked >= P.blocked_threshold || ns == 0u) {
             if (wl) {
-                if (COUNT) { cnt.prims++; cnt.prim_waves += first_active_lane(); }
+                if (COUNT && P.count_mode == 0u) { cnt.prims++; cnt.prim_waves += first_active_lane(); }
                 uint32_t e;
                 if (PAIRS) e = leaf_stack[nq - 1u][threadIdx.x];
                 else e = nq == 3u ? q2 : (nq == 2u ? q1 : q0);
@@ -1701,8 +1713,15 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                 uint4 hd;
                 Geom G;
                 load_prim(S, prim, hd, G);
+                if (COUNT && P.count_mode != 0u) { // one class only: its lane tests, and the runs that hold a lane of it
+                    const uint32_t kind = hd.x & 15u;
+                    const bool mine = P.count_mode == 1u ? (kind >= DP_XY_RECT && kind <= DP_BOX) : (kind <= DP_MOVING_SPHERE);
+                    const unsigned long long m = __ballot(mine);
+                    if (mine) cnt.prims++;
+                    if (m != 0ull && (uint32_t)(__ffsll((long long)__ballot(1)) - 1) == lane) cnt.prim_waves++;
+                }
                 float Tinv[12] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                if (e & RT_LEAF_XFORM) { // issued together with the loads of the primitive
+                if ((CL & RT_CL_XFORM) && (e & RT_LEAF_XFORM)) { // issued together with the loads of the primitive
                     float4 m0 = S.prim_inv[3u * prim], m1 = S.prim_inv[3u * prim + 1u], m2 = S.prim_inv[3u * prim + 2u];
                     Tinv[0] = m0.x; Tinv[1] = m0.y; Tinv[2] = m0.z; Tinv[3] = m0.w; Tinv[4] = m1.x; Tinv[5] = m1.y;
                     Tinv[6] = m1.z; Tinv[7] = m1.w; Tinv[8] = m2.x; Tinv[9] = m2.y; Tinv[10] = m2.z; Tinv[11] = m2.w;
@@ -1725,7 +1744,7 @@ __global__ void __launch_bounds__(256, (NESTED ? 4 : 6)) rt_extend_kernel(DevSce
                     node = __float_as_uint(G.g[0]) + layout_base(S, d) + set;
                     end = node + __float_as_uint(G.g[1]);
                 } else {
-                    surface_leaf<false>(Tinv, prim, hd, G, o, d, time, t_min, t_max, inst_rank, inst_xf, best, 0.0f, 0u);
+                    surface_leaf<false, CL>(Tinv, prim, hd, G, o, d, time, t_min, t_max, inst_rank, inst_xf, best, 0.0f, 0u);
                 }
             }
             continue;
@@ -2124,7 +2143,7 @@ __global__ void __launch_bounds__(1024) rt_compact_scan_kernel(uint32_t* __restr
     __syncthreads();
     const uint32_t total = counts[n_blocks];
     const uint32_t n2 = RT_COMPACT_SLOTS(total, n_slots);
-    for (uint32_t s = total + t; s < n2; s += 1024u) to[(size_t)n2 + s] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // plane 1
+    for (uint32_t s = total + t; s < n2; s += 1024u) to[QPI(n2, 1, s)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // plane 1
 }
 __global__ void __launch_bounds__(256) rt_compact_move_kernel(PathPool pool, const uint32_t* __restrict__ offsets, float4* __restrict__ to) {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
@@ -2139,11 +2158,11 @@ __global__ void __launch_bounds__(256) rt_compact_move_kernel(PathPool pool, con
     uint32_t rank = (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63u)) - 1ull));
     for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) rank += wave_n[w];
     const size_t d = (size_t)offsets[blockIdx.x] + rank, n = RT_COMPACT_SLOTS(offsets[gridDim.x], pool.n_slots);
-    to[d] = QP(pool, 0, s);
-    to[n + d] = p1;
-    to[2 * n + d] = QP(pool, 2, s);
-    to[3 * n + d] = QP(pool, 3, s); // a slot on hold keeps its settled hit
-    if (__float_as_uint(p1.w) & DEPTH_HAS_COLOR) to[4 * n + d] = QP(pool, 4, s);
+    to[QPI(n, 0, d)] = QP(pool, 0, s);
+    to[QPI(n, 1, d)] = p1;
+    to[QPI(n, 2, d)] = QP(pool, 2, s);
+    to[QPI(n, 3, d)] = QP(pool, 3, s); // a slot on hold keeps its settled hit
+    if (__float_as_uint(p1.w) & DEPTH_HAS_COLOR) to[QPI(n, 4, d)] = QP(pool, 4, s);
 }
 
 // accum[pixel] (+)= radiance of the pixel's paths of this batch, added in column order like the sample loop of draw!
@@ -2285,11 +2304,34 @@ extern "C" void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, cons
     uint32_t shade_blocks = (pool->n_slots + SHADE_BLOCK - 1u) / SHADE_BLOCK;
     if (timing) (void)hipEventRecord(timing[0], stream);
     const bool nested = S->nested != 0u, pairs = !nested && S->use_pairs != 0u;
+    static const bool extend_blocks_per_cu = std::getenv("RT_AMD_EXTEND_BLOCKS_PER_CU") != nullptr; // the caller's grid as it is
+    static const bool low_occupancy = std::getenv("RT_AMD_EXTEND_SIX") != nullptr; // six workgroups per CU whatever the variant could hold (measurements)
     if (count && nested) hipLaunchKernelGGL((rt_extend_kernel<true, true, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
     else if (count && pairs) hipLaunchKernelGGL((rt_extend_kernel<true, false, true>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
     else if (count) hipLaunchKernelGGL((rt_extend_kernel<true, false, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
     else if (nested) hipLaunchKernelGGL((rt_extend_kernel<false, true, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
-    else if (pairs) hipLaunchKernelGGL((rt_extend_kernel<false, false, true>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    else if (pairs) {
+        // the variant compiled for the scene's classes of primitives: the first of the list that covers them
+        const uint32_t have = S->classes;
+#define EXTEND_VARIANT(CL, BLOCKS)                                                                                               \
+        if ((have & ~(uint32_t)(CL)) == 0u) {                                                                                        \
+            if (S->pair_depth <= 16u && !low_occupancy) {                                                                            \
+                const uint32_t blocks = extend_blocks_per_cu ? extend_blocks : extend_blocks / 6u * (uint32_t)(BLOCKS);              \
+                hipLaunchKernelGGL((rt_extend_kernel<false, false, true, (CL), (BLOCKS), 16u>), dim3(blocks), dim3(256), 0, stream,  \
+                                   *S, *P, *pool, d_sync, d_counters);                                                               \
+            } else {                                                                                                                 \
+                hipLaunchKernelGGL((rt_extend_kernel<false, false, true, (CL), 6, RT_PAIR_STACK>), dim3(extend_blocks), dim3(256),   \
+                                   0, stream, *S, *P, *pool, d_sync, d_counters);                                                    \
+            }                                                                                                                        \
+        } else
+        EXTEND_VARIANT(RT_CL_SPHERE, 8)
+        EXTEND_VARIANT(RT_CL_TRI, 7)
+        EXTEND_VARIANT(RT_CL_RECT | RT_CL_BOX | RT_CL_XFORM, 7)
+        EXTEND_VARIANT(RT_CL_SPHERE | RT_CL_MOVING | RT_CL_RECT | RT_CL_BOX | RT_CL_XFORM, 6)
+        EXTEND_VARIANT(RT_CL_ALL, 6)
+        {}
+#undef EXTEND_VARIANT
+    }
     else hipLaunchKernelGGL((rt_extend_kernel<false, false, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
     if (before_shade) (void)hipStreamWaitEvent(stream, before_shade, 0);
     if (timing) (void)hipEventRecord(timing[1], stream);
