@@ -182,6 +182,7 @@ int fill_params(const float background[3], int width, int height, int max_depth,
     P->fetch_threshold = (uint32_t)env_int("RT_AMD_FETCH_THRESHOLD", 28);
     P->step_dropout = (uint32_t)env_int("RT_AMD_STEP_DROPOUT", 12);
     P->count_mode = (uint32_t)env_int("RT_AMD_COUNT_MODE", 0);
+    P->box_spread = std::getenv("RT_AMD_BOX_SPREAD") ? (uint32_t)std::min(10, std::atoi(std::getenv("RT_AMD_BOX_SPREAD"))) : 10u;
     P->regroup = std::getenv("RT_AMD_NO_REGROUP") ? 0u : 1u;
     if (!std::getenv("RT_AMD_NO_BIN")) P->regroup |= 2u;
     return RT_OK;

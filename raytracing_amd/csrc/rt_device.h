@@ -5,7 +5,7 @@
 //   nodes   : 16 B per node = one uint4: the box as six IEEE halves, one word per axis (near | far << 16: the plane a
 //             ray of the layout's octant meets first, then the other one; layout 0 = min | max << 16) of the bounds
 //             times node_scale, rounded strictly outward, and a link word w:
-//             leaves carry RT_NODE_LEAF | (primitive index + 1) | RT_LEAF_INSTANCE / RT_LEAF_XFORM flags, interior nodes
+//             leaves carry RT_NODE_LEAF | (primitive index + 1) | RT_LEAF_INSTANCE / RT_LEAF_XFORM / RT_LEAF_BOX flags, interior nodes
 //             the skip link.  Nodes are stored in depth-first pre-order.  Traversal is stackless: an interior node
 //             whose box is hit continues at node+1 (its first child), one that is missed at its skip link (the next
 //             node in pre-order that is not a descendant); a leaf always continues at node+1.  The walk of a tree is
@@ -36,7 +36,8 @@
 // ray taken into the frame of the Transform around that tree
 #define RT_BOX_OUTER 1u // flags: the first box is present
 #define RT_BOX_INNER 2u // flags: the second box is present
-#define RT_LEAF_PRIM_MASK 0x1FFFFFFFu // leaf word: primitive index + 1
+#define RT_LEAF_BOX 0x10000000u      // leaf word flag: the primitive is a Box (rt_extend_kernel spreads its six sides over lanes)
+#define RT_LEAF_PRIM_MASK 0x0FFFFFFFu // leaf word: primitive index + 1
 
 enum DevPrimKind {
     DP_SPHERE = 1,

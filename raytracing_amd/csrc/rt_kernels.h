@@ -53,6 +53,8 @@ struct RtRenderParams {
     uint32_t blocked_threshold;      // ... or once this many lanes cannot step before their leaves are tested
     uint32_t fetch_threshold;        // extend kernel: refill the wave once this many lanes are idle
     uint32_t step_dropout;           // extend kernel: leave the node-stepping loop after this many lanes dropped out
+    uint32_t box_spread;             // extend kernel: a leaf-block run with up to this many boxes (at most 10) has their six
+                                     // sides tested by six lanes each instead of one after the other; 0: never
     uint32_t count_mode;             // counting variant only: 0 = every leaf test; 1 = only rectangles and boxes, and the
                                      // leaf-block runs that hold one; 2 = only spheres, and the runs that hold one
     uint32_t regroup;                // shade kernel: bit 0 = shade the workgroup's slots in order of material type,

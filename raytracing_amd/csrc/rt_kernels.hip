@@ -257,26 +257,12 @@ __device__ __forceinline__ float triangle_t(const float* g, f3 o, f3 d, float t_
     return t;
 }
 
-// Distance to a surface primitive.  One code path per class so that a wave holding a mix of primitives does not
-// run one copy of the arithmetic per kind: spheres and moving spheres share sphere_t, the three rectangle kinds and
-// the six sides of a box share rect_t (ray components and bounds are selected per lane).
-// Tinv: the inverse matrix of the Transform around the primitive (used when field != 0)
-// CL: the classes of primitives the scene holds (RT_CL_*); the code of the others is left out.
+// Distance to a sphere, rectangle or box for a ray that is already in the primitive's frame (ro, rd).  One code path
+// per class so that a wave holding a mix of primitives does not run one copy of the arithmetic per kind: spheres and
+// moving spheres share sphere_t, the three rectangle kinds and the six sides of a box share rect_t (ray components and
+// bounds are selected per lane).  CL: the classes of primitives the scene holds (RT_CL_*); the code of the others is left out.
 template <uint32_t CL = RT_CL_ALL>
-__device__ __forceinline__ float surface_t(const float* Tinv, uint32_t kind, uint32_t field, const float* g, f3 o, f3 d,
-                                           float time, float t_min, float t_max, uint32_t& side, uint32_t& xf) {
-    side = 0;
-    if ((CL & RT_CL_TRI) && (CL == RT_CL_TRI || kind == DP_TRIANGLE)) {
-        f3 nrm;
-        float u, v;
-        return triangle_t(g, o, d, t_min, t_max, nrm, u, v);
-    }
-    f3 ro = o, rd = d;
-    if ((CL & RT_CL_XFORM) && field) { // Transform: src/transform.jl:104-105
-        ro = apply_point(Tinv, o);
-        rd = apply_vec(Tinv, d);
-        xf = field;
-    }
+__device__ __forceinline__ float framed_t(uint32_t kind, const float* g, f3 ro, f3 rd, float time, float t_min, float t_max, uint32_t& side) {
     if ((CL & RT_CL_SPHERE) && (!(CL & (RT_CL_RECT | RT_CL_BOX)) || kind <= DP_MOVING_SPHERE)) {
         f3 center = mk3(g[0], g[1], g[2]);
         float radius = g[3];
@@ -311,6 +297,25 @@ __device__ __forceinline__ float surface_t(const float* Tinv, uint32_t kind, uin
         if (t < best) { best = t; side = 5; t_max = t; }
     }
     return best;
+}
+
+// Distance to a surface primitive.  Tinv: the inverse matrix of the Transform around the primitive (used when field != 0)
+template <uint32_t CL = RT_CL_ALL>
+__device__ __forceinline__ float surface_t(const float* Tinv, uint32_t kind, uint32_t field, const float* g, f3 o, f3 d,
+                                           float time, float t_min, float t_max, uint32_t& side, uint32_t& xf) {
+    side = 0;
+    if ((CL & RT_CL_TRI) && (CL == RT_CL_TRI || kind == DP_TRIANGLE)) {
+        f3 nrm;
+        float u, v;
+        return triangle_t(g, o, d, t_min, t_max, nrm, u, v);
+    }
+    f3 ro = o, rd = d;
+    if ((CL & RT_CL_XFORM) && field) { // Transform: src/transform.jl:104-105
+        ro = apply_point(Tinv, o);
+        rd = apply_vec(Tinv, d);
+        xf = field;
+    }
+    return framed_t<CL>(kind, g, ro, rd, time, t_min, t_max, side);
 }
 
 // ------------------------------------------------------------------ closest hit over the whole scene
@@ -1608,6 +1613,7 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
     // not change its closest hit.  Both stacks take their stores unconditionally at the top; only the counts say what stays.
     __shared__ uint32_t pair_stack[PAIRS ? STACK : 1u][256];
     __shared__ uint32_t leaf_stack[PAIRS ? PAIR_LEAVES : 1u][256];
+    __shared__ __attribute__((aligned(16))) float box_data[(PAIRS && (CL & RT_CL_BOX)) ? 4u : 1u][(PAIRS && (CL & RT_CL_BOX)) ? 10u : 1u][20]; // per wave: the boxes a leaf-block run spreads over its lanes (16 words each, four of padding against bank conflicts)
     uint32_t sp = 0;
     Closest best = {INF, 0xFFFFFFFFu, 0u, 0u};
     for (;;) {
@@ -1703,12 +1709,27 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
         // ---- queued leaves: once enough lanes hold one, or too many lanes cannot step before theirs are tested
         const uint32_t n_blocked = (uint32_t)__popcll(__ballot(wl && !ws));
         if (nl >= P.leaf_threshold || n_blocked >= P.blocked_threshold || ns == 0u) {
+            // SPREAD: the boxes of this run, if they are few, are not tested by their own lanes one side after the other
+            // (six exact rectangle tests for a handful of lanes while the rest of the wave waits) but by six lanes each,
+            // any lanes: lane j of the wave takes side j % 6 of box j / 6, gets the box and its lane's ray through
+            // ds_bpermute, runs the one rectangle test, and the box's lane reads the six distances back and takes the
+            // closest in the order of src/box.jl:43-83 (strict <, so the first of equal distances stays) -- the same six
+            // results combined the same way.
+            constexpr bool SPREAD = PAIRS && (CL & RT_CL_BOX) != 0u;
+            uint32_t e = 0u;
             if (wl) {
-                if (COUNT && P.count_mode == 0u) { cnt.prims++; cnt.prim_waves += first_active_lane(); }
-                uint32_t e;
                 if (PAIRS) e = leaf_stack[nq - 1u][threadIdx.x];
                 else e = nq == 3u ? q2 : (nq == 2u ? q1 : q0);
                 nq -= 1u;
+            }
+            const unsigned long long m_box = SPREAD ? __ballot(wl && (e & RT_LEAF_BOX)) : 0ull;
+            const uint32_t n_box = (uint32_t)__popcll(m_box);
+            const bool spread = SPREAD && n_box != 0u && n_box <= P.box_spread; // (wave-uniform)
+            const bool box_lane = spread && wl && (e & RT_LEAF_BOX);
+            const uint32_t wave = threadIdx.x >> 6;
+            const uint32_t my_box = SPREAD ? __builtin_amdgcn_mbcnt_hi((uint32_t)(m_box >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_box, 0u)) : 0u;
+            if (wl) {
+                if (COUNT && P.count_mode == 0u) { cnt.prims++; cnt.prim_waves += first_active_lane(); }
                 uint32_t prim = (e & RT_LEAF_PRIM_MASK) - 1u;
                 uint4 hd;
                 Geom G;
@@ -1743,8 +1764,68 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
                     box_frame(S, o, d, R);
                     node = __float_as_uint(G.g[0]) + layout_base(S, d) + set;
                     end = node + __float_as_uint(G.g[1]);
+                } else if (SPREAD) {
+                    // surface_leaf() with the ray taken into the primitive's frame once, for boxes that are spread and
+                    // for everything else alike
+                    const uint32_t kind = hd.x & 15u;
+                    uint32_t side = 0u, xf = inst_xf;
+                    float t;
+                    if ((CL & RT_CL_TRI) && kind == DP_TRIANGLE) {
+                        f3 nrm;
+                        float u, v;
+                        t = triangle_t(G.g, o, d, t_min, t_max, nrm, u, v);
+                    } else {
+                        f3 ro = o, rd = d;
+                        const uint32_t field = hd.x >> 8;
+                        if ((CL & RT_CL_XFORM) && field) { // Transform: src/transform.jl:104-105
+                            ro = apply_point(Tinv, o);
+                            rd = apply_vec(Tinv, d);
+                            xf = field;
+                        }
+                        if (box_lane) {
+                            // the ray in the box's frame, the box, the bound and what a hit will be recorded with,
+                            // where any lane of the wave can read them
+                            float4* q = reinterpret_cast<float4*>(box_data[wave][my_box]);
+                            q[0] = make_float4(ro.x, ro.y, ro.z, rd.x);
+                            q[1] = make_float4(rd.y, rd.z, G.g[0], G.g[1]);
+                            q[2] = make_float4(G.g[2], G.g[3], G.g[4], G.g[5]);
+                            q[3] = make_float4(t_max, __uint_as_float(prim), __uint_as_float((xf << 3) | ((hd.x & DP_TYPE_MASK) << 24)),
+                                               __uint_as_float(hd.z + inst_rank));
+                            t = INF; // (the spread stage below considers the box)
+                        } else {
+                            t = framed_t<CL>(kind, G.g, ro, rd, time, t_min, t_max, side);
+                        }
+                    }
+                    consider(best, t_max, t, prim, side | (xf << 3) | ((hd.x & DP_TYPE_MASK) << 24), hd.z + inst_rank);
                 } else {
                     surface_leaf<false, CL>(Tinv, prim, hd, G, o, d, time, t_min, t_max, inst_rank, inst_xf, best, 0.0f, 0u);
+                }
+            }
+            if (SPREAD && spread) {
+                const uint32_t r = (lane * 43u) >> 8, f = lane - 6u * r; // lane / 6, lane % 6
+                const float4* q = reinterpret_cast<const float4*>(box_data[wave][r < n_box ? r : 0u]);
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+                const float tm = box_data[wave][r < n_box ? r : 0u][12];
+                const float v[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+                // side f of src/box.jl:13-22: 0, 1 = the planes z = max.z, min.z over (x, y); 2, 3 = y = max.y, min.y over
+                // (x, z); 4, 5 = x = max.x, min.x over (y, z) -- the arguments box_t gives rect_t for that side
+                const bool pz = f < 2u, px = f >= 4u, lo = (f & 1u) != 0u;
+                const float ok = pz ? v[2] : (px ? v[0] : v[1]), dk = pz ? v[5] : (px ? v[3] : v[4]);
+                const float oa = px ? v[1] : v[0], da = px ? v[4] : v[3];
+                const float ob = pz ? v[1] : v[2], db = pz ? v[4] : v[5];
+                const float a0 = px ? v[7] : v[6], a1 = px ? v[10] : v[9];
+                const float b0 = pz ? v[7] : v[8], b1 = pz ? v[10] : v[11];
+                const float kk = lo ? (pz ? v[8] : (px ? v[6] : v[7])) : (pz ? v[11] : (px ? v[9] : v[10]));
+                float t = rect_t(ok, dk, oa, da, ob, db, a0, a1, b0, b1, kk, t_min, tm);
+                if (r >= n_box) t = INF;
+                float tf[6];
+                for (uint32_t k = 0; k < 6u; ++k) tf[k] = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((6u * my_box + k) << 2), __float_as_int(t)));
+                if (box_lane) {
+                    float bt = INF;
+                    uint32_t side = 0u;
+                    for (uint32_t k = 0; k < 6u; ++k) if (tf[k] < bt) { bt = tf[k]; side = k; }
+                    const float4 w = reinterpret_cast<const float4*>(box_data[wave][my_box])[3];
+                    consider(best, t_max, bt, __float_as_uint(w.y), side | __float_as_uint(w.z), __float_as_uint(w.w));
                 }
             }
             continue;

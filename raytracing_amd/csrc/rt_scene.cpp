@@ -305,7 +305,8 @@ struct Builder {
             uint32_t head = H.prims[3 * (size_t)prim].x;
             bool instance = (head & 15u) == DP_INSTANCE;
             set_ref_boxes(prim, nested ? (inl ? inl->clip_box : nullptr) : leaf_box, nested ? leaf_box : nullptr);
-            const uint32_t flags = instance ? RT_LEAF_INSTANCE : ((head >> 8) ? RT_LEAF_XFORM : 0u);
+            const uint32_t flags = instance ? RT_LEAF_INSTANCE
+                                            : (((head & 15u) != DP_TRIANGLE && (head >> 8)) ? RT_LEAF_XFORM : 0u) | ((head & 15u) == DP_BOX ? RT_LEAF_BOX : 0u);
             if (inl) { // the object-frame box of the leaf in the world frame; the reference's box is that of the whole nested tree
                 double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
                 double M[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};

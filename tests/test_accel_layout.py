@@ -12,7 +12,7 @@ from raytracing_amd import hittables as H
 from raytracing_amd.render import scene_layout, scene_layout_pairs
 
 LEAF = 0x80000000
-PRIM_MASK = 0x1FFFFFFF
+PRIM_MASK = 0x0FFFFFFF
 SCENES = ["cornell_box", "cornell_smoke_box", "cover1", "cu_cover2", "cover2", "teapot"]
 
 
