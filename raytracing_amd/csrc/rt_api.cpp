@@ -207,6 +207,8 @@ int rt_device_count(int* count) {
     return RT_OK;
 }
 
+static int static_scratch(int device, unsigned char** out);
+
 int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     if (!desc || !out) return rt_fail(RT_EINVAL, "rt_scene_create: null argument");
     *out = nullptr;
@@ -223,6 +225,13 @@ int rt_scene_create(const rtSceneDesc* desc, int device, rtScene** out) {
     e = hipSetDevice(device);
     if (e != hipSuccess) { delete s; return rt_fail(RT_EHIP, "hipSetDevice failed: %s", hipGetErrorString(e)); }
     s->device = device;
+    {   // The address of the static scratch array on this device is asked for here, at set-up: the runtime brings the
+        // array's code object to a device when something of it is first used there (and takes the array's 53 MiB then),
+        // so that rt_render_accumulate_static finds it resident and takes no device memory even on its first call.  A
+        // failure is not this call's: the static entry point reports it if it is ever used.
+        unsigned char* unused = nullptr;
+        (void)static_scratch(device, &unused);
+    }
     st = upload_nodes(s);
     if (st == RT_OK) st = upload(s, H.prims, &s->dev.prims);
     if (st == RT_OK) st = upload(s, H.prim_inv, &s->dev.prim_inv);

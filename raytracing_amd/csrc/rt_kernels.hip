@@ -1028,10 +1028,13 @@ __device__ __forceinline__ Closest next_hit_after(const DevScene& S, f3 wo, f3 w
 #define SETTLE_LIST 6
 // first: the closest of all the hits the surfaces report (what the walk of the device tree found).  MEDIA: the scene's
 // constant media take part, `key` names the ray's random stream.
+// list: room for SETTLE_LIST entries of the calling lane's own (in LDS: a list indexed by a variable would live in
+// scratch memory if it were a local array, and the kernels that settle hits are kept free of scratch so that their
+// first launch on a queue does not make the runtime set scratch memory aside -- rt_render_accumulate_static must not
+// cause device memory to be taken).
 template <bool MEDIA>
 __device__ __forceinline__ Closest front_sequence(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_hi, Closest first,
-                                                  const RngKey& key) {
-    Closest list[SETTLE_LIST];
+                                                  const RngKey& key, Closest* list) {
     int n = 0;
     float stands_t = INF;     // distance of the closest hit that stands (N)
     float front = t_min;      // largest box-entry distance among the hits in front of their boxes
@@ -1141,22 +1144,23 @@ __device__ __forceinline__ Closest front_sequence(const DevScene& S, f3 o, f3 d,
 // The closest hit of the whole scene as the reference has it, from `best`, the closest surface the walk of the device
 // tree found.  Short way, almost always: the surface stands (hit_stands) and the media go through the reference's
 // reduction with it (media_closest).  Otherwise the reference's sequence is played over the hits at the front.
-__device__ __forceinline__ void settle_hit(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_hi, const RngKey& key, Closest& best) {
+__device__ __forceinline__ void settle_hit(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_hi, const RngKey& key, Closest& best,
+                                           Closest* list) {
     if (best.t != INF && !hit_stands(S, best.prim, (best.sx >> 3) & 0x3FFFFFFu, o, d, t_min, t_hi, best.t)) {
-        if (S.n_media == 0u) best = front_sequence<false>(S, o, d, time, t_min, t_hi, best, key);
-        else best = front_sequence<true>(S, o, d, time, t_min, t_hi, best, key);
+        if (S.n_media == 0u) best = front_sequence<false>(S, o, d, time, t_min, t_hi, best, key, list);
+        else best = front_sequence<true>(S, o, d, time, t_min, t_hi, best, key, list);
         return;
     }
     if (S.n_media == 0u) return;
     Closest with_media = best;
     if (media_closest(S, o, d, time, t_min, t_hi, key, with_media)) best = with_media;
-    else best = front_sequence<true>(S, o, d, time, t_min, t_hi, best, key);
+    else best = front_sequence<true>(S, o, d, time, t_min, t_hi, best, key, list);
 }
 
 // closest hit of one ray per lane (used by the ray parity hook)
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const DevScene& S, f3 o, f3 d, float time, float t_min, float t_max,
-                                            const RngKey& key, Closest& best, Counters& cnt, bool active) {
+                                            const RngKey& key, Closest& best, Counters& cnt, bool active, Closest* list) {
     Walker W;
     walker_start(W, S, o, d, time, t_min, t_max);
     Vote V = {16u, 64u};
@@ -1168,7 +1172,7 @@ __device__ __forceinline__ void closest_hit(const DevScene& S, f3 o, f3 d, float
         else { if (wl) walker_leaf<COUNT>(W, S, cnt); }
     }
     best = W.best;
-    if (active) settle_hit(S, o, d, time, t_min, t_max, key, best);
+    if (active) settle_hit(S, o, d, time, t_min, t_max, key, best, list);
 }
 
 // ------------------------------------------------------------------ hit completion (only for the winner)
@@ -1613,7 +1617,9 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
     // not change its closest hit.  Both stacks take their stores unconditionally at the top; only the counts say what stays.
     __shared__ uint32_t pair_stack[PAIRS ? STACK : 1u][256];
     __shared__ uint32_t leaf_stack[PAIRS ? PAIR_LEAVES : 1u][256];
-    __shared__ __attribute__((aligned(16))) float box_data[(PAIRS && (CL & RT_CL_BOX)) ? 4u : 1u][(PAIRS && (CL & RT_CL_BOX)) ? 10u : 1u][20]; // per wave: the boxes a leaf-block run spreads over its lanes (16 words each, four of padding against bank conflicts)
+    // (not in the variant that also carries the triangle code: there the stage's live values no longer fit the registers)
+    constexpr bool SPREAD_BOXES = PAIRS && (CL & RT_CL_BOX) != 0u && (CL & RT_CL_TRI) == 0u;
+    __shared__ __attribute__((aligned(16))) float box_data[SPREAD_BOXES ? 4u : 1u][SPREAD_BOXES ? 10u : 1u][20]; // per wave: the boxes a leaf-block run spreads over its lanes (16 words each, four of padding against bank conflicts)
     uint32_t sp = 0;
     Closest best = {INF, 0xFFFFFFFFu, 0u, 0u};
     for (;;) {
@@ -1715,7 +1721,7 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
             // ds_bpermute, runs the one rectangle test, and the box's lane reads the six distances back and takes the
             // closest in the order of src/box.jl:43-83 (strict <, so the first of equal distances stays) -- the same six
             // results combined the same way.
-            constexpr bool SPREAD = PAIRS && (CL & RT_CL_BOX) != 0u;
+            constexpr bool SPREAD = SPREAD_BOXES;
             uint32_t e = 0u;
             if (wl) {
                 if (PAIRS) e = leaf_stack[nq - 1u][threadIdx.x];
@@ -1923,6 +1929,7 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
 // sync[RT_REDO_COUNT]: number of entries in pool.redo, reset by the last workgroup to finish (sync[RT_REDO_COUNT + 1]
 // counts the finished ones).
 __global__ void __launch_bounds__(256) rt_redo_kernel(DevScene S, RtRenderParams P, PathPool pool, uint32_t* __restrict__ sync) {
+    __shared__ Closest settle_list[256][SETTLE_LIST]; // per lane: the list front_sequence keeps
     const uint32_t n = __hip_atomic_load(sync + RT_REDO_COUNT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // The slots are dealt to the waves first and to the lanes of a wave last: every slot takes its own way through the
     // loops below, and the lanes of one wave would run those ways one after the other.
@@ -1937,7 +1944,7 @@ __global__ void __launch_bounds__(256) rt_redo_kernel(DevScene S, RtRenderParams
         RngKey key;
         path_key(P, (__float_as_uint(p1.w) >> DEPTH_COLUMN_SHIFT) & DEPTH_COLUMN_MASK, __float_as_uint(QP(pool, 2, slot).w), key);
         key.bounce = (uint32_t)P.max_depth - (__float_as_uint(p1.w) & DEPTH_MASK);
-        settle_hit(S, o, d, p0.w, 0.001f, INF, key, best);
+        settle_hit(S, o, d, p0.w, 0.001f, INF, key, best, settle_list[threadIdx.x]);
         QP(pool, 3, slot) = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(best.rank | RANK_SETTLED));
     }
     __syncthreads();
@@ -2306,7 +2313,8 @@ __global__ void __launch_bounds__(256) rt_trace_rays_kernel(DevScene S, const fl
     RngKey key = {(uint32_t)k, 0u, seed32, 0u};
     Counters cnt = {0, 0, 0, 0, 0, 0};
     Closest best;
-    closest_hit<false>(S, o, d, time, t_min, t_max, key, best, cnt, active);
+    __shared__ Closest settle_list[256][SETTLE_LIST];
+    closest_hit<false>(S, o, d, time, t_min, t_max, key, best, cnt, active, settle_list[threadIdx.x]);
     if (!active) return;
     HitRec h;
     h.p = mk3(INF, INF, INF); h.n = mk3(0, 0, 0); h.u = 0; h.v = 0; h.front = false; h.material = 0;
@@ -2348,6 +2356,7 @@ __global__ void __launch_bounds__(256) rt_trace_paths_kernel(DevScene S, RtCamer
     f3 c = mk3(0.0f, 0.0f, 0.0f);
     f3 bgc = mk3(P.background[0], P.background[1], P.background[2]);
     Walker W;
+    __shared__ Closest settle_list[256][SETTLE_LIST];
     walker_start(W, S, o, d, time, 0.001f, INF);
     Vote V = {P.leaf_threshold, 16u};
     for (;;) {
@@ -2361,7 +2370,7 @@ __global__ void __launch_bounds__(256) rt_trace_paths_kernel(DevScene S, RtCamer
             f3 no, nd;
             if (done) c = ps.color;
             else {
-                settle_hit(S, W.o, W.d, W.time, 0.001f, INF, key, W.best);
+                settle_hit(S, W.o, W.d, W.time, 0.001f, INF, key, W.best, settle_list[threadIdx.x]);
                 done = shade<true>(S, W.o, W.d, W.time, W.best, ps, bgc, key, c, no, nd);
             }
             if (done) alive = false;

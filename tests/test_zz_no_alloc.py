@@ -38,9 +38,11 @@ def test_static_entry_point_equals_the_allocating_one():
         # first call: more paths than the static pool has slots (672 x 480 x 6 = 1.9 M paths, 256 Ki slots), three shards
         W, H, pat = 672, 480, rt.Halton_sequence32(18)
         want = _sums(dev, dev.accumulate, cam, pat, bg, W, H, 1, 3)
-        got = _sums(dev, dev.accumulate_static, cam, pat, bg, W, H, 1, 3)
+        took = []
+        got = _sums(dev, dev.accumulate_static, cam, pat, bg, W, H, 1, 3, watch=took)
         np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
         assert np.isfinite(got).all() and got.max() > 0
+        assert took[0] <= 0, "rt_render_accumulate_static took %d bytes of device memory (first, large call)" % took[0]
         # second call in a row, smaller input (fewer paths than slots): what the first call left in the array must not show,
         # and the call must not take device memory
         W2, H2, pat2 = 96, 64, rt.Halton_sequence32(5)
@@ -51,9 +53,27 @@ def test_static_entry_point_equals_the_allocating_one():
         assert took[0] <= 0, "rt_render_accumulate_static took %d bytes of device memory" % took[0]
         # a third, again larger, with several column batches (1 Mi pixels: two columns per batch of the 2 Mi entry buffer)
         W3, H3, pat3 = 1024, 1024, rt.Halton_sequence32(5)
-        got3 = _sums(dev, dev.accumulate_static, cam, pat3, bg, W3, H3)
+        took = []
+        got3 = _sums(dev, dev.accumulate_static, cam, pat3, bg, W3, H3, watch=took)
         want3 = _sums(dev, dev.accumulate, cam, pat3, bg, W3, H3)
         np.testing.assert_array_equal(got3.view(np.uint32), want3.view(np.uint32))
+        assert took[0] <= 0, "rt_render_accumulate_static took %d bytes of device memory (several column batches)" % took[0]
+        # a camera far outside the scene: the call rebuilds the node boxes for that distance before it renders (the one
+        # route on which the static entry point reaches the tree builder); that, too, must take no device memory -- the
+        # builder works in memory the scene handle got when it was created
+        from raytracing_amd.hittables import Camera, Vec3
+        far = Camera(Vec3(478.0, 278.0, -60000.0), Vec3(0.0, 0.0, -1.0), Vec3(0, 1, 0), 2.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+        took = []
+        got4 = _sums(dev, dev.accumulate_static, far, pat2, bg, 160, 160, watch=took)
+        want4 = _sums(dev, dev.accumulate, far, pat2, bg, 160, 160)
+        np.testing.assert_array_equal(got4.view(np.uint32), want4.view(np.uint32))
+        assert took[0] <= 0, "rt_render_accumulate_static took %d bytes of device memory (rebuild for a far camera)" % took[0]
+        assert got4.max() > 0       # (the scene is in the picture)
+        # ... and back: the next call from the scene's own camera gets the tight boxes again, still without memory
+        took = []
+        got5 = _sums(dev, dev.accumulate_static, cam, pat2, bg, W2, H2, watch=took)
+        np.testing.assert_array_equal(got5.view(np.uint32), want2.view(np.uint32))
+        assert took[0] <= 0, "rt_render_accumulate_static took %d bytes of device memory (rebuild on the way back)" % took[0]
         # an empty shard is a zero sum
         zero = _sums(dev, dev.accumulate_static, cam, pat2, bg, W2, H2, 7, 8)
         assert not zero.any()
