@@ -104,7 +104,7 @@ int upload_nodes(rtScene* s) {
     s->dev.pairs = s->d_pairs;
     s->dev.n_pairs = H.pairs_per_layout;
     // (and when a record's byte offset fits 32 bits: 16 layouts of 32-byte records)
-    s->dev.use_pairs = (H.pairs_per_layout && H.pairs_per_layout < (1u << 23) && depth <= RT_PAIR_STACK && !std::getenv("RT_AMD_NO_PAIRS")) ? 1u : 0u;
+    s->dev.use_pairs = (H.pairs_per_layout && H.pairs_per_layout < (1u << 23) && depth <= RT_PAIR_STACK_DEEP && !std::getenv("RT_AMD_NO_PAIRS")) ? 1u : 0u;
     s->dev.pair_depth = depth;
     s->dev.nodes = s->d_nodes;
     s->dev.n_nodes = H.nodes_per_layout;

@@ -26,7 +26,8 @@
 #include <stdint.h>
 
 #define RT_NODE_NONE 0xFFFFFFFFu    // "no node" (e.g. no outer tree to return to)
-#define RT_PAIR_STACK 20u          // entries of the LDS stack of a lane that walks the pair nodes: deepest tree walked that way
+#define RT_PAIR_STACK 20u          // entries of the LDS stack of a lane that walks the pair nodes at six workgroups per CU
+#define RT_PAIR_STACK_DEEP 32u     // ... at four workgroups per CU: the deepest tree walked through pair nodes (beyond: the stackless walk)
 #define RT_NODE_LEAF 0x80000000u    // node link word: the node is a leaf
 #define RT_LEAF_INSTANCE 0x40000000u // leaf word flag: the primitive is a nested tree (Transform{BVHTree})
 #define RT_LEAF_XFORM 0x20000000u    // leaf word flag: the primitive sits in a Transform (prim_inv holds its inverse matrix)

@@ -2397,6 +2397,8 @@ extern "C" void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, cons
     static const bool extend_blocks_per_cu = std::getenv("RT_AMD_EXTEND_BLOCKS_PER_CU") != nullptr; // the caller's grid as it is
     static const bool low_occupancy = std::getenv("RT_AMD_EXTEND_SIX") != nullptr; // six workgroups per CU whatever the variant could hold (measurements)
     if (count && nested) hipLaunchKernelGGL((rt_extend_kernel<true, true, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
+    else if (count && pairs && S->pair_depth > RT_PAIR_STACK)
+        hipLaunchKernelGGL((rt_extend_kernel<true, false, true, RT_CL_ALL, 4, RT_PAIR_STACK_DEEP>), dim3(extend_blocks / 6u * 4u), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
     else if (count && pairs) hipLaunchKernelGGL((rt_extend_kernel<true, false, true>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
     else if (count) hipLaunchKernelGGL((rt_extend_kernel<true, false, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
     else if (nested) hipLaunchKernelGGL((rt_extend_kernel<false, true, false>), dim3(extend_blocks), dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);
@@ -2409,9 +2411,13 @@ extern "C" void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, cons
                 const uint32_t blocks = extend_blocks_per_cu ? extend_blocks : extend_blocks / 6u * (uint32_t)(BLOCKS);              \
                 hipLaunchKernelGGL((rt_extend_kernel<false, false, true, (CL), (BLOCKS), 16u>), dim3(blocks), dim3(256), 0, stream,  \
                                    *S, *P, *pool, d_sync, d_counters);                                                               \
-            } else {                                                                                                                 \
+            } else if (S->pair_depth <= RT_PAIR_STACK) {                                                                             \
                 hipLaunchKernelGGL((rt_extend_kernel<false, false, true, (CL), 6, RT_PAIR_STACK>), dim3(extend_blocks), dim3(256),   \
                                    0, stream, *S, *P, *pool, d_sync, d_counters);                                                    \
+            } else { /* a deep tree (a large mesh): 35 KB of stacks a workgroup, four workgroups per CU */                           \
+                const uint32_t blocks = extend_blocks_per_cu ? extend_blocks : extend_blocks / 6u * 4u;                              \
+                hipLaunchKernelGGL((rt_extend_kernel<false, false, true, RT_CL_ALL, 4, RT_PAIR_STACK_DEEP>), dim3(blocks),           \
+                                   dim3(256), 0, stream, *S, *P, *pool, d_sync, d_counters);                                         \
             }                                                                                                                        \
         } else
         EXTEND_VARIANT(RT_CL_SPHERE, 8)

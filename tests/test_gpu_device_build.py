@@ -211,3 +211,41 @@ def test_pictures_do_not_depend_on_the_builder(name, monkeypatch):
     img_host, on_dev2 = picture()
     assert on_dev == 1 and on_dev2 == 0
     assert np.array_equal(img_dev.view(np.uint32), img_host.view(np.uint32))
+
+
+@pytest.mark.parametrize("ratio,count,walk", [(8.0, 28, "pairs"), (4.0, 40, "pairs"), (4.0, 48, "stackless")])
+def test_deep_trees_walk_the_pair_nodes_with_the_deep_stack(ratio, count, walk):
+    """Spheres whose sizes and distances grow geometrically make the surface-area heuristic split one off at a time: a
+    tree of depth 23 / 29 / beyond 32 from a few dozen primitives.  Up to 20 levels the walk over pair nodes keeps its
+    stack in 20 KB of LDS a workgroup, up to 32 in 32 KB (four workgroups per CU instead of six), beyond that the
+    stackless walk takes over; whichever walks, hits and pictures are the oracle's."""
+    import oracle_ffi as O
+    m = rt.Material(rt.Lambertian, rt.Vec3(0.6, 0.6, 0.6))
+    world = [rt.Sphere(rt.Vec3(ratio ** k, 0.0, 0.0), 0.2 * ratio ** k, m) for k in range(count)]
+    dev, ref = rt.DeviceScene(world), O.OracleScene(world)
+    try:
+        build = dev.layout()[3]
+        in_use = dev.pairs()[1]
+        assert (build.max_depth > 20) and in_use == (walk == "pairs") and (build.max_depth <= 32) == (walk == "pairs"), (build.max_depth, in_use)
+        rng = np.random.default_rng(5)
+        k = rng.integers(0, count, 4096)                # every ray aims near one of the spheres, from a few radii away
+        centre = np.stack([ratio ** k.astype(np.float64), np.zeros(4096), np.zeros(4096)], axis=1)
+        radius = (0.2 * ratio ** k.astype(np.float64))[:, None]
+        away = rng.normal(size=(4096, 3))
+        away /= np.linalg.norm(away, axis=1, keepdims=True)
+        o = centre + away * radius * rng.uniform(1.5, 30.0, (4096, 1))
+        d = centre + rng.normal(size=(4096, 3)) * radius * 0.6 - o
+        rays = np.concatenate([o, d, np.full((4096, 1), 0.5)], axis=1).astype(np.float32)
+        a, b = ref.trace_rays(rays), dev.trace_rays(rays)
+        for k in ("prim_id", "sub_id", "front"):
+            np.testing.assert_array_equal(a[k], b[k])
+        for k in ("t", "normal", "uv"):
+            np.testing.assert_array_equal(np.ascontiguousarray(a[k]).view(np.uint32), np.ascontiguousarray(b[k]).view(np.uint32))
+        assert (a["prim_id"] >= 0).sum() > 500 and len(set(a["prim_id"])) > 12
+        origin = rt.Vec3(-3.0, 1.0, -6.0)
+        cam = rt.Camera(origin, origin - rt.Vec3(20.0, 0.0, 0.0), rt.Vec3(0, 1, 0), 70.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+        pat, bg = rt.Halton_sequence32(6), rt.Vec3(0.7, 0.8, 1.0)
+        img, _ = dev.render(cam, pat, bg, 96, 96)            # (through rt_extend_kernel: the variant with the deep stack)
+        np.testing.assert_array_equal(img.view(np.uint32), ref.render(cam, pat, bg, 96, 96).view(np.uint32))
+    finally:
+        dev.close()
