@@ -147,12 +147,20 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # RT_BENCH_BACKEND=gloo is a rehearsal of the N > 1 control flow on a host with fewer GPUs than ranks: the ranks then
+    # share the devices there are and the all-reduce goes through host memory (its numbers mean nothing)
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     if world_size > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the path tracer has no CPU fallback")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -240,7 +248,7 @@ def main():
             # HBM bytes per launch and the VALU readings come from PMC passes (rocprofv3 --pmc, run apart from the timed
             # run as the counters need); the committed summary of the latest passes is read here and named as the source
             pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and world_size == 1:  # (the passes were made with one GPU tracing every column)
                 with open(pmc) as f:
                     prof = json.load(f)
                 roofline["traffic"] = prof.get(args.scene)
