@@ -1582,7 +1582,9 @@ __global__ void __launch_bounds__(256) rt_init_kernel(RtCameraDev cam, const flo
 // Which block runs is a wave-wide vote.  Constant media are left to rt_shade_kernel.  NESTED: the scene holds nested
 // trees (Transform{BVHTree}); without them the state for the outer ray is not carried.
 #define LEAF_QUEUE 3u
+#ifndef PAIR_LEAVES
 #define PAIR_LEAVES 3u // leaves a lane can have waiting in the walk over pair nodes (a step adds up to two)
+#endif
 // CL: the classes of surface primitives the scene holds (RT_CL_*; the leaf block carries only their code).  BLOCKS:
 // workgroups per CU the kernel is compiled for (registers per lane = 512 / BLOCKS, rounded down to a multiple of 8).
 // STACK: entries of a lane's stack in the walk over pair nodes (the tree must be no deeper): with 16 instead of
