@@ -1724,6 +1724,13 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
             // closest in the order of src/box.jl:43-83 (strict <, so the first of equal distances stays) -- the same six
             // results combined the same way.
             constexpr bool SPREAD = SPREAD_BOXES;
+            if (COUNT && PAIRS && P.count_mode == 3u) {
+                // lanes without a ray (or done with theirs) and lanes with a second leaf waiting that is not a box
+                const bool idle = !busy || fin;
+                const bool second = wl && nq >= 2u && !(leaf_stack[nq - 2u][threadIdx.x] & RT_LEAF_BOX);
+                const uint32_t ni = (uint32_t)__popcll(__ballot(idle)), n2 = (uint32_t)__popcll(__ballot(second));
+                if (first_active_lane()) { cnt.prims += ni; cnt.nodes += n2; cnt.node_waves += min(ni, n2); cnt.prim_waves++; }
+            }
             uint32_t e = 0u;
             if (wl) {
                 if (PAIRS) e = leaf_stack[nq - 1u][threadIdx.x];
@@ -1742,7 +1749,7 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
                 uint4 hd;
                 Geom G;
                 load_prim(S, prim, hd, G);
-                if (COUNT && P.count_mode != 0u) { // one class only: its lane tests, and the runs that hold a lane of it
+                if (COUNT && (P.count_mode == 1u || P.count_mode == 2u)) { // one class only: its lane tests, and the runs that hold a lane of it
                     const uint32_t kind = hd.x & 15u;
                     const bool mine = P.count_mode == 1u ? (kind >= DP_XY_RECT && kind <= DP_BOX) : (kind <= DP_MOVING_SPHERE);
                     const unsigned long long m = __ballot(mine);
@@ -1850,7 +1857,7 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
             bool stepping = ws;
             do {
                 if (PAIRS && stepping) {
-                    if (COUNT) { cnt.nodes += 2; cnt.node_waves += first_active_lane(); }
+                    if (COUNT && P.count_mode != 3u) { cnt.nodes += 2; cnt.node_waves += first_active_lane(); }
                     const uint4* rec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.pairs) + (node << 5)); // (32-bit offset: fewer than 2^27 records)
                     const uint4 qa = rec[0], qb = rec[1];
                     const uint32_t top = pair_stack[sp ? sp - 1u : 0u][threadIdx.x]; // (wanted only if this step ends a subtree)
