@@ -89,31 +89,6 @@ def test_pictures_do_not_depend_on_the_walk(name, monkeypatch):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-def test_deep_tree_is_walked_without_the_stack():
-    """spheres whose sizes and distances grow sixfold from one to the next make a tree as deep as it has leaves (the
-    surface-area heuristic peels the largest off at every level): deeper than the stack of the walk over pair nodes, so
-    the scene is walked without one -- with the same picture as the oracle's"""
-    import oracle_ffi as O
-    mat = rt.Material(rt.Lambertian, rt.Vec3(0.6, 0.5, 0.4))
-    world = [rt.Sphere(rt.Vec3(6.0 ** k, 0.0, 0.0), 6.0 ** k / 4.0, mat) for k in range(-14, 18)]
-    dev = rt.DeviceScene(world)
-    ref = O.OracleScene(world)
-    try:
-        depth, used = dev.layout()[3].max_depth, dev.pairs()[1]
-        cam = rt.Camera((300.0, 200.0, -900.0), (0.0, 200.0, -900.0), (0, 1, 0), 60.0, 1.0)
-        ids = np.array([(i, j, n) for j in range(0, 48, 3) for i in range(0, 48, 3) for n in range(2)], np.int32)
-        pat = rt.Halton_sequence32(2)
-        a = ref.trace_paths(cam, pat, (0.7, 0.8, 1.0), 48, 48, ids)
-        b = dev.trace_paths(cam, pat, (0.7, 0.8, 1.0), 48, 48, ids)
-        img = dev.render(cam, pat, (0.7, 0.8, 1.0), 48, 48)[0]
-        want = ref.render(cam, pat, (0.7, 0.8, 1.0), 48, 48)
-    finally:
-        dev.close()
-    assert depth > 20 and not used, (depth, used)
-    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-    assert np.abs(img - want).max() < 1e-5 and img.std() > 0.01
-
-
 def test_far_camera_rebuild_on_the_device():
     """a camera far outside the scene makes the library rebuild the node sets for its distance (boxes of objects taken out
     of nested trees are padded in proportion): with the device builder that is a kernel launch, and it gives what the
