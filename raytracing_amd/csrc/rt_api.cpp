@@ -68,6 +68,9 @@ struct rtScene {
 
 #define SYNC_WORDS RT_SYNC_WORDS // word 0: slot dispenser; words 2..: per-bounce activity flags; then the path dispensers
 #define BOUNCE_BATCH 16u   // bounces enqueued between two looks at the active count
+#define RT_LARGE_POOL_SLOTS (8u << 20) // a pool with more slots than this is looked at more often (render_frame)
+#define RT_POOL_SLOTS (4u << 20)        // slots of the path pool: frames of fewer than 4 * RT_POOL_SLOTS_LARGE paths
+#define RT_POOL_SLOTS_LARGE (32u << 20) // ... and longer frames (rt_render_accumulate)
 
 namespace {
 
@@ -448,7 +451,6 @@ static int render_frame(rtScene* s, const rtCamera* camera, const float* pattern
         pool.n_slots = frame_slots;
         pool.q = ws.pool;
         bool tail = false; // the device reported that no unstarted path is left
-        const uint32_t batch = BOUNCE_BATCH;
         P.k_begin = k0;
         P.k_end = k0 + cols < n_shard_samples ? k0 + cols : n_shard_samples;
         P.n_paths = (P.k_end - P.k_begin) * P.n_pixels;
@@ -469,7 +471,14 @@ static int render_frame(rtScene* s, const rtCamera* camera, const float* pattern
         HIP_TRY(hipGetLastError());
         // Bounce loop: the device reports after every bounce how many slots still hold a ray; the host enqueues
         // bounces in batches and stops after the first batch that ends with none.
-        for (uint64_t bounce = 0;; bounce += batch) {
+        // Bounces enqueued before the host looks again (and, once the unstarted paths have run out, compacts the pool): fewer
+        // while the pool is large -- every bounce without a compaction then walks over the slots that have emptied since the
+        // last one, which costs in proportion to the pool, and a launch over 32 Mi slots takes milliseconds, so the look
+        // costs nothing.  (Cutting the batch in which the paths run out to end there, from the dispensers' counters, was
+        // measured on top: no gain.)
+        const uint32_t batch_large = (uint32_t)std::min(std::max(env_int("RT_AMD_LARGE_POOL_BATCH", 8), 1), (int)BOUNCE_BATCH);
+        for (uint64_t bounce = 0;;) {
+            const uint32_t batch = pool.n_slots > RT_LARGE_POOL_SLOTS ? batch_large : BOUNCE_BATCH;
             HIP_TRY(hipMemsetAsync(ws.sync + 2, 0, BOUNCE_BATCH * sizeof(uint32_t), stream));
             // The slots on hold are settled between two batches.  rt_extend_kernel leaves them alone and rt_redo_kernel
             // touches nothing else, so the two run side by side (the redo is a few lone lanes walking the tree); the
@@ -522,6 +531,7 @@ static int render_frame(rtScene* s, const rtCamera* camera, const float* pattern
             }
             if (s->h_sync[0] == 0u) break;
             tail = s->h_sync[2] != 0u;
+            bounce += batch;
             if (bounce > ((uint64_t)P.n_paths / pool.n_slots + 2ull) * 64ull + 4096ull)
                 return rt_fail(RT_EHIP, "bounce loop did not terminate");
         }
@@ -578,14 +588,24 @@ int rt_render_accumulate(rtScene* s, const rtCamera* camera, const float* patter
     int st = accumulate_prologue("rt_render_accumulate", s, camera, pattern, n, sample_first, sample_stride, background, width,
                                  height, max_depth, seed, d_accum, stream, &P, &n_shard_samples, &empty);
     if (st != RT_OK || empty) return st;
-    // Slots in flight: enough rays per launch to fill the machine many times over.  Default 4 Mi: the four live planes of
-    // the path pool (64 bytes per slot) then just stay inside the 256 MB Infinity Cache between the kernel that writes them
-    // and the one that reads them; throughput falls by 6 % right above that and does not come back before 10 Mi slots.
+    // Slots in flight: enough rays per launch to fill the machine many times over.  With 4 Mi slots the four live planes of
+    // the path pool (64 bytes per slot) just stay inside the 256 MB Infinity Cache between the kernel that writes them
+    // and the one that reads them; throughput falls by 4 % right above that.  It comes back at 12 Mi and goes beyond at 24-48
+    // Mi: every launch of rt_extend_kernel ends with its waves running empty (a quarter of the step iterations of a 4 Mi
+    // launch are taken after the slots ran out, with half the lanes holding a ray), and a launch eight times as long
+    // has an eighth of those ends -- extend -11 %, shade +9 % (its 112 bytes per slot now come from HBM), +3 % in all.  A
+    // larger pool drains for longer once the unstarted paths have run out, so a frame has to be long enough for it, and
+    // the end of a launch is as long as the longest walk, so the tree has to be deep enough for there to be something to
+    // win: cover1 (485 spheres under an open sky) +24 %, teapot +4 %, cu_cover2 +3 %, cover2 +-0, but the Cornell boxes
+    // (a dozen primitives, walks of a few steps) -6 ... -11 % at any frame length.  32 Mi slots for frames of 128 Mi paths
+    // or more (cu_cover2 800x800: 210 pattern columns) over a tree at least eight levels deep, 4 Mi otherwise.
     // The radiance of every path is kept until its pixel is summed, so the frame is cut into batches of pattern
     // columns whose radiance buffer fits the budget (default 12 GiB of the 288 GB).
     Workspace ws{};
     const uint64_t budget = (uint64_t)env_int("RT_AMD_RADIANCE_MIB", 12 * 1024) * 1024ull * 1024ull;
-    st = plan_frame(P, n_shard_samples, (uint32_t)env_int("RT_AMD_SLOTS", 4 * 1024 * 1024), budget / sizeof(float4), &ws.n_slots, &ws.cols);
+    const uint64_t frame_paths = (uint64_t)P.n_pixels * n_shard_samples;
+    const int slots_default = frame_paths >= 4ull * RT_POOL_SLOTS_LARGE && s->dev.pair_depth >= 8u ? (int)RT_POOL_SLOTS_LARGE : (int)RT_POOL_SLOTS;
+    st = plan_frame(P, n_shard_samples, (uint32_t)env_int("RT_AMD_SLOTS", slots_default), budget / sizeof(float4), &ws.n_slots, &ws.cols);
     if (st != RT_OK) return st;
     st = ensure(&s->d_pattern, &s->pattern_cap, (size_t)2 * (size_t)n);
     if (st != RT_OK) return st;

@@ -1856,8 +1856,13 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
             uint32_t n_step;
             bool stepping = ws;
             do {
+                if (COUNT && PAIRS && P.count_mode == 4u && lane == 0u) {
+                    // lanes without a ray per step iteration, before and after the wave has run out of slots to fetch
+                    const uint32_t idle = 64u - (uint32_t)__popcll(m_busy);
+                    if (exhausted) { cnt.nodes += idle; cnt.prim_waves++; } else { cnt.prims += idle; cnt.node_waves++; }
+                }
                 if (PAIRS && stepping) {
-                    if (COUNT && P.count_mode != 3u) { cnt.nodes += 2; cnt.node_waves += first_active_lane(); }
+                    if (COUNT && P.count_mode < 3u) { cnt.nodes += 2; cnt.node_waves += first_active_lane(); }
                     const uint4* rec = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.pairs) + (node << 5)); // (32-bit offset: fewer than 2^27 records)
                     const uint4 qa = rec[0], qb = rec[1];
                     const uint32_t top = pair_stack[sp ? sp - 1u : 0u][threadIdx.x]; // (wanted only if this step ends a subtree)

@@ -159,6 +159,46 @@ def test_edge_cases(scenes, monkeypatch):
     assert st.rays >= st.paths > 0 and st.node_visits > st.rays
 
 
+def test_the_size_of_the_slot_pool_changes_no_picture(monkeypatch):
+    """A frame of 128 Mi paths or more over a tree at least eight levels deep is given 32 Mi slots instead of 4 Mi (fewer,
+    longer launches: fewer ends of launches with the waves running empty), looked at every 8 bounces instead of every
+    16 and compacted as often once its unstarted paths have run out; a scene of a dozen primitives keeps 4 Mi whatever its
+    length.  Which slot a path lives in changes nothing: pictures are equal bit for bit."""
+    def frame(dev, kw, n, W, H, slots):
+        if slots:
+            monkeypatch.setenv("RT_AMD_SLOTS", str(slots))
+        else:
+            monkeypatch.delenv("RT_AMD_SLOTS", raising=False)
+        img, st = dev.render(kw["camera"], rt.Halton_sequence32(n), kw["background"], W, H, flags=ffi.RT_FLAG_TIMING)
+        return img, st.extend_launches
+    world, kw = rt.get_scene("cu_cover2", spp=1)
+    dev = rt.DeviceScene(world)
+    try:
+        # a pool above 8 Mi slots with fewer slots than paths: the large pool's batches, its dispensers and its compaction
+        a, la = frame(dev, kw, 80, 512, 512, 9 << 20)
+        b, lb = frame(dev, kw, 80, 512, 512, 0)
+        np.testing.assert_array_equal(bits(a), bits(b))
+        assert la % 8 == 0 and lb % 16 == 0
+        # 210 columns of 800 x 800 are 128.2 Mi paths: the library takes 32 Mi slots by itself
+        c, lc = frame(dev, kw, 210, 800, 800, 0)
+        d, ld = frame(dev, kw, 210, 800, 800, 4 << 20)
+        np.testing.assert_array_equal(bits(c), bits(d))
+        assert lc * 3 < ld, (lc, ld)
+    finally:
+        dev.close()
+    world, kw = rt.get_scene("cornell_box", spp=1)
+    dev = rt.DeviceScene(world)
+    try:
+        e, le = frame(dev, kw, 840, 400, 400, 0)           # as many paths, a tree of three levels: 4 Mi slots
+        f, lf = frame(dev, kw, 840, 400, 400, 4 << 20)
+        g, lg = frame(dev, kw, 840, 400, 400, 32 << 20)
+        np.testing.assert_array_equal(bits(e), bits(f))
+        np.testing.assert_array_equal(bits(e), bits(g))
+        assert le == lf and lg * 3 < lf, (le, lf, lg)
+    finally:
+        dev.close()
+
+
 @pytest.mark.parametrize("width,height", [(1024, 64), (512, 128)])
 def test_uneven_columns_drain_every_path_dispenser(width, height, monkeypatch):
     """An image whose width is a multiple of 256 maps every path dispenser to a fixed band of columns; here the left
