@@ -577,6 +577,18 @@ __device__ __forceinline__ void consider(Closest& best, float& t_max, float t, u
         t_max = t;
     }
 }
+// The same for a walk that keeps only `held` = primitive | box side << 28 of its closest hit (all ones: none) beside the
+// bound, which is that hit's distance: transform index, material type and rank are the primitive's own (no nested trees)
+// and are read from its record when the hit is published; a tie in distance -- rare -- reads the held primitive's rank.
+__device__ __forceinline__ void consider_packed(const DevScene& S, uint32_t& held, float& t_max, float t, uint32_t prim, uint32_t side,
+                                                uint32_t rank) {
+    bool take = t < t_max;
+    if (t == t_max && t != INF && held != 0xFFFFFFFFu) take = rank > S.prims[3u * (held & RT_LEAF_PRIM_MASK)].z;
+    if (take) {
+        t_max = t;
+        held = prim | (side << 28);
+    }
+}
 __device__ __forceinline__ void consider(Closest& best, float& t_max, float t, uint32_t prim, uint32_t sx, uint32_t rank,
                                          float floor_t, uint32_t floor_rank) {
     if (t > floor_t || (t == floor_t && rank < floor_rank)) consider(best, t_max, t, prim, sx, rank);
@@ -1624,6 +1636,9 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
     __shared__ __attribute__((aligned(16))) float box_data[SPREAD_BOXES ? 4u : 1u][SPREAD_BOXES ? 10u : 1u][20]; // per wave: the boxes a leaf-block run spreads over its lanes (16 words each, four of padding against bank conflicts)
     uint32_t sp = 0;
     Closest best = {INF, 0xFFFFFFFFu, 0u, 0u};
+    // PACKED (the walk over pair nodes: no nested trees): the closest hit is kept as one word beside t_max (consider_packed)
+    constexpr bool PACKED = PAIRS && !NESTED;
+    uint32_t held = 0xFFFFFFFFu;
     for (;;) {
         // ---- end of a nested tree with nothing pending: back to the outer ray (cheap, no vote needed)
         if (NESTED && busy && nq == 0u && node == end && ret != RT_NODE_NONE) {
@@ -1645,6 +1660,16 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
             if (COUNT) cnt.bounce_waves += first_active_lane();
             if (fin) {
                 // publish the hit for the shade kernel (the material type is bits 29-31 of sx)
+                if (PACKED) {
+                    best.t = INF; best.prim = 0xFFFFFFFFu; best.sx = 0u; best.rank = 0u;
+                    if (held != 0xFFFFFFFFu) {
+                        best.t = t_max;
+                        best.prim = held & RT_LEAF_PRIM_MASK;
+                        const uint4 hd = S.prims[3u * best.prim];
+                        best.sx = (held >> 28) | (((hd.x & 15u) == DP_TRIANGLE ? 0u : hd.x >> 8) << 3) | ((hd.x & DP_TYPE_MASK) << 24);
+                        best.rank = hd.z;
+                    }
+                }
                 QP(pool, 3, slot) = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(best.rank));
                 if (COUNT) cnt.rays++;
                 busy = false;
@@ -1704,6 +1729,7 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
                                 ret = RT_NODE_NONE;
                                 inst_rank = 0; inst_xf = 0;
                                 best.t = INF; best.prim = 0xFFFFFFFFu; best.sx = 0u; best.rank = 0u;
+                                held = 0xFFFFFFFFu;
                             }
                         }
                     }
@@ -1805,13 +1831,18 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
                             q[1] = make_float4(rd.y, rd.z, G.g[0], G.g[1]);
                             q[2] = make_float4(G.g[2], G.g[3], G.g[4], G.g[5]);
                             q[3] = make_float4(t_max, __uint_as_float(prim), __uint_as_float((xf << 3) | ((hd.x & DP_TYPE_MASK) << 24)),
-                                               __uint_as_float(hd.z + inst_rank));
+                                               __uint_as_float(hd.z + inst_rank)); // (SPREAD implies PACKED: the third word is not used)
                             t = INF; // (the spread stage below considers the box)
                         } else {
                             t = framed_t<CL>(kind, G.g, ro, rd, time, t_min, t_max, side);
                         }
                     }
-                    consider(best, t_max, t, prim, side | (xf << 3) | ((hd.x & DP_TYPE_MASK) << 24), hd.z + inst_rank);
+                    consider_packed(S, held, t_max, t, prim, side, hd.z);
+                } else if (PACKED) {
+                    const uint32_t kind = hd.x & 15u;
+                    uint32_t side = 0u, xf = 0u;
+                    const float t = surface_t<CL>(Tinv, kind, kind == DP_TRIANGLE ? 0u : hd.x >> 8, G.g, o, d, time, t_min, t_max, side, xf);
+                    consider_packed(S, held, t_max, t, prim, side, hd.z);
                 } else {
                     surface_leaf<false, CL>(Tinv, prim, hd, G, o, d, time, t_min, t_max, inst_rank, inst_xf, best, 0.0f, 0u);
                 }
@@ -1840,7 +1871,7 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
                     uint32_t side = 0u;
                     for (uint32_t k = 0; k < 6u; ++k) if (tf[k] < bt) { bt = tf[k]; side = k; }
                     const float4 w = reinterpret_cast<const float4*>(box_data[wave][my_box])[3];
-                    consider(best, t_max, bt, __float_as_uint(w.y), side | __float_as_uint(w.z), __float_as_uint(w.w));
+                    consider_packed(S, held, t_max, bt, __float_as_uint(w.y), side, __float_as_uint(w.w));
                 }
             }
             continue;
@@ -2437,7 +2468,7 @@ extern "C" void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, cons
         EXTEND_VARIANT(RT_CL_SPHERE, 8)
         EXTEND_VARIANT(RT_CL_TRI, 7)
         EXTEND_VARIANT(RT_CL_RECT | RT_CL_BOX | RT_CL_XFORM, 7)
-        EXTEND_VARIANT(RT_CL_SPHERE | RT_CL_MOVING | RT_CL_RECT | RT_CL_BOX | RT_CL_XFORM, 6)
+        EXTEND_VARIANT(RT_CL_SPHERE | RT_CL_MOVING | RT_CL_RECT | RT_CL_BOX | RT_CL_XFORM, 7)
         EXTEND_VARIANT(RT_CL_ALL, 6)
         {}
 #undef EXTEND_VARIANT
