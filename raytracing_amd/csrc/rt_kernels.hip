@@ -1612,8 +1612,10 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
     const uint32_t disp_first = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % RT_SLOT_DISP;
     uint32_t disp_tries = 0;
     bool exhausted = false;
-    bool busy = false;
-    uint32_t slot = 0;
+    // A lane without a ray has slot == NO_SLOT, an empty leaf queue and node == end: it looks like a lane whose walk is
+    // over, so the votes below need no test of their own for it.
+    constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
+    uint32_t slot = NO_SLOT;
     f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 1.0f);
     BoxRay R; // the ray in the form the box test wants
     box_frame(S, o, d, R);
@@ -1641,19 +1643,26 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
     uint32_t held = 0xFFFFFFFFu;
     for (;;) {
         // ---- end of a nested tree with nothing pending: back to the outer ray (cheap, no vote needed)
-        if (NESTED && busy && nq == 0u && node == end && ret != RT_NODE_NONE) {
+        if (NESTED && nq == 0u && node == end && ret != RT_NODE_NONE) {
             o = so; d = sd;
             box_frame(S, o, d, R);
             node = ret; end = ret_end;
             ret = RT_NODE_NONE;
             inst_rank = 0; inst_xf = 0;
         }
-        const bool fin = busy && nq == 0u && node == end;
-        const bool wl = busy && nq != 0u;
-        const bool ws = busy && node != end && (PAIRS ? nq <= PAIR_LEAVES - 2u : nq < LEAF_QUEUE) && !(NESTED && nq != 0u && (q0 & RT_LEAF_INSTANCE));
-        const uint32_t n_need = (uint32_t)__popcll(__ballot(!busy || fin));
-        const uint32_t nl = (uint32_t)__popcll(__ballot(wl));
-        const uint32_t ns = (uint32_t)__popcll(__ballot(ws));
+        // the votes: each comparison is voted on by itself (its lane mask as the comparison leaves it) and the masks are
+        // combined by scalar instructions; a vote on a combined condition would cost two vector instructions more
+        const bool over = nq == 0u && node == end;  // the walk is over, or there is no ray
+        const bool fin = over && slot != NO_SLOT;
+        const bool wl = nq != 0u;
+        const bool ws = node != end && (PAIRS ? nq <= PAIR_LEAVES - 2u : nq < LEAF_QUEUE) && !(NESTED && nq != 0u && (q0 & RT_LEAF_INSTANCE));
+        const unsigned long long m_nq0 = __builtin_amdgcn_ballot_w64(nq == 0u), m_end = __builtin_amdgcn_ballot_w64(node == end);
+        const unsigned long long m_room = __builtin_amdgcn_ballot_w64(PAIRS ? nq <= PAIR_LEAVES - 2u : nq < LEAF_QUEUE);
+        const unsigned long long m_enter = NESTED ? __builtin_amdgcn_ballot_w64((q0 & RT_LEAF_INSTANCE) != 0u) & ~m_nq0 : 0ull;
+        const unsigned long long m_wl = ~m_nq0, m_ws = ~m_end & m_room & ~m_enter;
+        const uint32_t n_need = (uint32_t)__popcll(m_nq0 & m_end);
+        const uint32_t nl = (uint32_t)__popcll(m_wl);
+        const uint32_t ns = (uint32_t)__popcll(m_ws);
 
         // ---- retire finished rays and fetch new ones once enough lanes are idle
         if ((n_need >= P.fetch_threshold && !exhausted) || (nl | ns) == 0u) {
@@ -1672,10 +1681,10 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
                 }
                 QP(pool, 3, slot) = make_float4(best.t, __uint_as_float(best.prim), __uint_as_float(best.sx), __uint_as_float(best.rank));
                 if (COUNT) cnt.rays++;
-                busy = false;
+                slot = NO_SLOT;
             }
             if (!exhausted) {
-                unsigned long long m = __ballot(!busy);
+                unsigned long long m = __builtin_amdgcn_ballot_w64(slot == NO_SLOT);
                 if (cur >= cur_end) { // take the next chunk of slots
                     // RT_SLOT_DISP counters on separate cache lines, each handing out one contiguous share of the slots
                     // (a single counter serialises thousands of atomics per launch); a wave starts at "its" counter and
@@ -1703,14 +1712,13 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
                     else { cur = base; cur_end = min(base + EXTEND_CHUNK, limit); }
                 }
                 if (!exhausted) {
-                    if (!busy) {
+                    if (slot == NO_SLOT) {
                         uint32_t sidx = cur + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                         if (sidx < cur_end) {
                             float4 p1 = QP(pool, 1, sidx), p0 = QP(pool, 0, sidx);
                             asm volatile("" : "+v"(p0.x), "+v"(p1.x)); // both loads in flight before the depth is looked at
                             if (((__float_as_uint(p1.w) & (DEPTH_MASK | DEPTH_HOLD)) - 1u) < DEPTH_MASK) { // holds a ray, not on hold
                                 slot = sidx;
-                                busy = true;
                                 o = mk3(p0.x, p0.y, p0.z); d = mk3(p1.x, p1.y, p1.z);
                                 box_frame(S, o, d, R);
                                 time = p0.w;
@@ -1736,12 +1744,12 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
                     cur = min(cur + (uint32_t)__popcll(m), cur_end);
                 }
             }
-            if (exhausted && __ballot(busy) == 0ull) break;
+            if (exhausted && __builtin_amdgcn_ballot_w64(slot != NO_SLOT) == 0ull) break;
             continue;
         }
 
         // ---- queued leaves: once enough lanes hold one, or too many lanes cannot step before theirs are tested
-        const uint32_t n_blocked = (uint32_t)__popcll(__ballot(wl && !ws));
+        const uint32_t n_blocked = (uint32_t)__popcll(m_wl & ~m_ws);
         if (nl >= P.leaf_threshold || n_blocked >= P.blocked_threshold || ns == 0u) {
             // SPREAD: the boxes of this run, if they are few, are not tested by their own lanes one side after the other
             // (six exact rectangle tests for a handful of lanes while the rest of the wave waits) but by six lanes each,
@@ -1752,9 +1760,9 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
             constexpr bool SPREAD = SPREAD_BOXES;
             if (COUNT && PAIRS && P.count_mode == 3u) {
                 // lanes without a ray (or done with theirs) and lanes with a second leaf waiting that is not a box
-                const bool idle = !busy || fin;
+                const bool idle = over;
                 const bool second = wl && nq >= 2u && !(leaf_stack[nq - 2u][threadIdx.x] & RT_LEAF_BOX);
-                const uint32_t ni = (uint32_t)__popcll(__ballot(idle)), n2 = (uint32_t)__popcll(__ballot(second));
+                const uint32_t ni = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(idle)), n2 = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(second));
                 if (first_active_lane()) { cnt.prims += ni; cnt.nodes += n2; cnt.node_waves += min(ni, n2); cnt.prim_waves++; }
             }
             uint32_t e = 0u;
@@ -1763,7 +1771,7 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
                 else e = nq == 3u ? q2 : (nq == 2u ? q1 : q0);
                 nq -= 1u;
             }
-            const unsigned long long m_box = SPREAD ? __ballot(wl && (e & RT_LEAF_BOX)) : 0ull;
+            const unsigned long long m_box = SPREAD ? __builtin_amdgcn_ballot_w64((e & RT_LEAF_BOX) != 0u) : 0ull; // (e is 0 without a leaf)
             const uint32_t n_box = (uint32_t)__popcll(m_box);
             const bool spread = SPREAD && n_box != 0u && n_box <= P.box_spread; // (wave-uniform)
             const bool box_lane = spread && wl && (e & RT_LEAF_BOX);
@@ -1778,9 +1786,9 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
                 if (COUNT && (P.count_mode == 1u || P.count_mode == 2u)) { // one class only: its lane tests, and the runs that hold a lane of it
                     const uint32_t kind = hd.x & 15u;
                     const bool mine = P.count_mode == 1u ? (kind >= DP_XY_RECT && kind <= DP_BOX) : (kind <= DP_MOVING_SPHERE);
-                    const unsigned long long m = __ballot(mine);
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
                     if (mine) cnt.prims++;
-                    if (m != 0ull && (uint32_t)(__ffsll((long long)__ballot(1)) - 1) == lane) cnt.prim_waves++;
+                    if (m != 0ull && (uint32_t)(__ffsll((long long)__builtin_amdgcn_ballot_w64(true)) - 1) == lane) cnt.prim_waves++;
                 }
                 float Tinv[12] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                 if ((CL & RT_CL_XFORM) && (e & RT_LEAF_XFORM)) { // issued together with the loads of the primitive
@@ -1883,13 +1891,13 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
             // t_max does not change in this loop: widened once like the far distance of a box (node_test), and held
             // against the entry distance by a comparison of its own
             const float t_far = __builtin_fmaf(fabsf(t_max), 4.8e-7f, t_max);
-            const unsigned long long m_busy = __builtin_amdgcn_ballot_w64(busy);
             uint32_t n_step;
             bool stepping = ws;
             do {
+                const unsigned long long m_idle = COUNT ? __builtin_amdgcn_ballot_w64(slot == NO_SLOT) : 0ull;
                 if (COUNT && PAIRS && P.count_mode == 4u && lane == 0u) {
                     // lanes without a ray per step iteration, before and after the wave has run out of slots to fetch
-                    const uint32_t idle = 64u - (uint32_t)__popcll(m_busy);
+                    const uint32_t idle = (uint32_t)__popcll(m_idle);
                     if (exhausted) { cnt.nodes += idle; cnt.prim_waves++; } else { cnt.prims += idle; cnt.node_waves++; }
                 }
                 if (PAIRS && stepping) {
@@ -1951,8 +1959,8 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
                 // then the comparisons' lane masks themselves, combined by scalar instructions
                 const bool more = node != end, room = PAIRS ? nq <= PAIR_LEAVES - 2u : nq < LEAF_QUEUE;
                 const bool enter = NESTED && nq != 0u && (q0 & RT_LEAF_INSTANCE);
-                stepping = busy && more && room && !enter;
-                n_step = (uint32_t)__popcll(m_busy & __builtin_amdgcn_ballot_w64(more) & __builtin_amdgcn_ballot_w64(room) &
+                stepping = more && room && !enter;
+                n_step = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(more) & __builtin_amdgcn_ballot_w64(room) &
                                             ~(NESTED ? __builtin_amdgcn_ballot_w64(enter) : 0ull));
             } while (n_step >= floor_lanes);
         }
