@@ -1705,9 +1705,10 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
                             break;
                         }
                     }
-                    base = (uint32_t)__shfl((int)base, 0);
-                    limit = (uint32_t)__shfl((int)limit, 0);
-                    disp_tries = (uint32_t)__shfl((int)disp_tries, 0);
+                    // (lane 0's values for the wave, in scalar registers: the cursor into the chunk is the same in every lane)
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    limit = (uint32_t)__builtin_amdgcn_readfirstlane((int)limit);
+                    disp_tries = (uint32_t)__builtin_amdgcn_readfirstlane((int)disp_tries);
                     if (base == 0xFFFFFFFFu) { exhausted = true; cur = cur_end = 0; }
                     else { cur = base; cur_end = min(base + EXTEND_CHUNK, limit); }
                 }
