@@ -1784,6 +1784,7 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
                 uint4 hd;
                 Geom G;
                 load_prim(S, prim, hd, G);
+                if (PACKED) asm volatile("" : "+v"(hd.y)); // (keeps the record's three 16-byte loads whole: split around the unused word, their registers need six copies to line up)
                 if (COUNT && (P.count_mode == 1u || P.count_mode == 2u)) { // one class only: its lane tests, and the runs that hold a lane of it
                     const uint32_t kind = hd.x & 15u;
                     const bool mine = P.count_mode == 1u ? (kind >= DP_XY_RECT && kind <= DP_BOX) : (kind <= DP_MOVING_SPHERE);
@@ -2475,10 +2476,10 @@ extern "C" void rt_launch_bounce(const DevScene* S, const RtCameraDev* cam, cons
             }                                                                                                                        \
         } else
         EXTEND_VARIANT(RT_CL_SPHERE, 8)
-        EXTEND_VARIANT(RT_CL_TRI, 7)
+        EXTEND_VARIANT(RT_CL_TRI, 8)
         EXTEND_VARIANT(RT_CL_RECT | RT_CL_BOX | RT_CL_XFORM, 7)
         EXTEND_VARIANT(RT_CL_SPHERE | RT_CL_MOVING | RT_CL_RECT | RT_CL_BOX | RT_CL_XFORM, 7)
-        EXTEND_VARIANT(RT_CL_ALL, 6)
+        EXTEND_VARIANT(RT_CL_ALL, 7)
         {}
 #undef EXTEND_VARIANT
     }
