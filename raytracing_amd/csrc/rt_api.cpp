@@ -69,6 +69,7 @@ struct rtScene {
 #define SYNC_WORDS RT_SYNC_WORDS // word 0: slot dispenser; words 2..: per-bounce activity flags; then the path dispensers
 #define BOUNCE_BATCH 16u   // bounces enqueued between two looks at the active count
 #define RT_LARGE_POOL_SLOTS (8u << 20) // a pool with more slots than this is looked at more often (render_frame)
+#define RT_TAIL_SMALL_POOL (64u << 10) // ... and one that is running empty, until it has shrunk to this
 #define RT_POOL_SLOTS (4u << 20)        // slots of the path pool: frames of fewer than 4 * RT_POOL_SLOTS_LARGE paths
 #define RT_POOL_SLOTS_LARGE (32u << 20) // ... and longer frames (rt_render_accumulate)
 
@@ -471,14 +472,25 @@ static int render_frame(rtScene* s, const rtCamera* camera, const float* pattern
         HIP_TRY(hipGetLastError());
         // Bounce loop: the device reports after every bounce how many slots still hold a ray; the host enqueues
         // bounces in batches and stops after the first batch that ends with none.
-        // Bounces enqueued before the host looks again (and, once the unstarted paths have run out, compacts the pool): fewer
-        // while the pool is large -- every bounce without a compaction then walks over the slots that have emptied since the
-        // last one, which costs in proportion to the pool, and a launch over 32 Mi slots takes milliseconds, so the look
-        // costs nothing.  (Cutting the batch in which the paths run out to end there, from the dispensers' counters, was
-        // measured on top: no gain.)
+        // Bounces enqueued before the host looks again (and, once the unstarted paths have run out, compacts the pool).
+        // While paths are left: 16, or 8 while the pool is large (a launch over 32 Mi slots takes milliseconds, so the look
+        // costs nothing).  Once they have run out, a fifth of the slots empties with every bounce, and a launch over
+        // emptied slots costs nearly what one over full slots does (the kernels still visit them): the pool is then looked
+        // at and compacted every 4 bounces until it is small.  To get there in time, the batch in which the paths will run
+        // out is cut to end where they do: the dispensers' counters say how many are left, the batch before how many a
+        // bounce starts.
         const uint32_t batch_large = (uint32_t)std::min(std::max(env_int("RT_AMD_LARGE_POOL_BATCH", 8), 1), (int)BOUNCE_BATCH);
+        const uint32_t batch_tail = (uint32_t)std::min(std::max(env_int("RT_AMD_TAIL_BATCH", 4), 1), (int)BOUNCE_BATCH);
+        uint64_t unstarted = P.n_paths > pool.n_slots ? (uint64_t)P.n_paths - pool.n_slots : 0ull;
+        double started_per_bounce = 0.0;
+        const bool predict = ws.may_allocate && unstarted != 0ull && !std::getenv("RT_AMD_NO_TAIL_PREDICTION");
         for (uint64_t bounce = 0;;) {
-            const uint32_t batch = pool.n_slots > RT_LARGE_POOL_SLOTS ? batch_large : BOUNCE_BATCH;
+            uint32_t batch = pool.n_slots > RT_LARGE_POOL_SLOTS ? batch_large : BOUNCE_BATCH;
+            if (predict && tail && pool.n_slots > RT_TAIL_SMALL_POOL) batch = batch_tail;
+            if (predict && !tail && started_per_bounce > 0.0) {
+                const double bounces_left = (double)unstarted / started_per_bounce + 1.0;
+                if (bounces_left < (double)batch) batch = (uint32_t)bounces_left;
+            }
             HIP_TRY(hipMemsetAsync(ws.sync + 2, 0, BOUNCE_BATCH * sizeof(uint32_t), stream));
             // The slots on hold are settled between two batches.  rt_extend_kernel leaves them alone and rt_redo_kernel
             // touches nothing else, so the two run side by side (the redo is a few lone lanes walking the tree); the
@@ -517,7 +529,19 @@ static int render_frame(rtScene* s, const rtCamera* camera, const float* pattern
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(s->h_sync, ws.sync + 1u + batch, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(s->h_sync + 2, ws.sync + RT_TAIL_FLAG, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            if (predict && !tail)
+                HIP_TRY(hipMemcpy2DAsync(s->h_sync + 8, sizeof(uint32_t), ws.sync + RT_DISP_BASE, RT_DISP_STRIDE * sizeof(uint32_t),
+                                         sizeof(uint32_t), P.n_disp, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
+            if (predict && !tail) {
+                uint64_t left = 0ull;
+                for (uint32_t c = 0; c < P.n_disp; ++c) {
+                    const uint32_t lim = rt_dispenser_limit(P.n_paths, P.n_disp, c);
+                    if (s->h_sync[8u + c] < lim) left += lim - s->h_sync[8u + c];
+                }
+                started_per_bounce = left < unstarted ? (double)(unstarted - left) / (double)batch : 0.0;
+                unstarted = left;
+            }
             if (timing) {
                 for (uint32_t b = 0; b < batch; ++b) {
                     float ms_e = 0.0f, ms_s = 0.0f;
@@ -530,7 +554,7 @@ static int render_frame(rtScene* s, const rtCamera* camera, const float* pattern
                 s->last_shade_launches += batch;
             }
             if (s->h_sync[0] == 0u) break;
-            tail = s->h_sync[2] != 0u;
+            tail = s->h_sync[2] != 0u || (predict && unstarted == 0ull); // (the device's flag, or every counter at its limit)
             bounce += batch;
             if (bounce > ((uint64_t)P.n_paths / pool.n_slots + 2ull) * 64ull + 4096ull)
                 return rt_fail(RT_EHIP, "bounce loop did not terminate");
