@@ -178,7 +178,13 @@ def test_the_size_of_the_slot_pool_changes_no_picture(monkeypatch):
         a, la = frame(dev, kw, 80, 512, 512, 9 << 20)
         b, lb = frame(dev, kw, 80, 512, 512, 0)
         np.testing.assert_array_equal(bits(a), bits(b))
-        assert la % 8 == 0 and lb % 16 == 0
+        # (the batch in which the unstarted paths run out is cut short, and the draining pool is compacted every 4 bounces:
+        # without either the same picture from fewer looks)
+        monkeypatch.setenv("RT_AMD_NO_TAIL_PREDICTION", "1")
+        b2, lb2 = frame(dev, kw, 80, 512, 512, 0)
+        monkeypatch.delenv("RT_AMD_NO_TAIL_PREDICTION")
+        np.testing.assert_array_equal(bits(b), bits(b2))
+        assert lb2 % 16 == 0 and lb != lb2, (lb, lb2)
         # 210 columns of 800 x 800 are 128.2 Mi paths: the library takes 32 Mi slots by itself
         c, lc = frame(dev, kw, 210, 800, 800, 0)
         d, ld = frame(dev, kw, 210, 800, 800, 4 << 20)
