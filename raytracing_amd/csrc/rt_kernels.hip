@@ -1697,7 +1697,6 @@ __global__ void __launch_bounds__(256, BLOCKS) rt_extend_kernel(DevScene S, RtRe
                             if (lo >= pool.n_slots) continue;
                             const uint32_t size = min(slot_share, pool.n_slots - lo);
                             uint32_t* ctr = head + RT_SLOT_DISP_BASE + c * RT_DISP_STRIDE;
-                            if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= size) continue;
                             const uint32_t v = atomicAdd(ctr, EXTEND_CHUNK);
                             if (v >= size) continue;
                             base = lo + v;
